@@ -1,0 +1,77 @@
+/*
+ * kdtree/kdtree.h -- public C API of the drop-in libkdtree.so built by this repository.
+ *
+ * Same 22 entry points, names, signatures and calling conventions as the reference's
+ * Utils/kdtree/include/kdtree/kdtree.h:39-122, so that Planner/src/corridor_finder.cpp
+ * (call sites :174,179,431-434,464-488,647,709,716,750,802,956-1015) links against it
+ * unchanged.  The implementation behind it is NOT a pointer tree on the host: points are
+ * mirrored into an SoA cloud in HBM and kd_nearest* / kd_nearest_range* run the HIP
+ * kernels of pct_engine (see include/pct_engine.h); the host keeps only the insertion
+ * topology needed to reproduce the reference's result ORDER for range queries.
+ *
+ * Behaviour kept from the reference (reference file: Utils/kdtree/src/kdtree.c):
+ *   - coordinates are stored as double; the *f variants widen float -> double (:211-242)
+ *   - kd_nearest*: exact 1-NN, d2 = ((dx*dx + dy*dy) + dz*dz) in fp64 without FMA
+ *     (:379-382); NULL for a NULL or empty tree (:412-413)
+ *   - kd_nearest_range*: hit iff d2 <= range*range (:273), far side of a split pruned
+ *     unless fabs(dx) < range (:283), iteration order = reverse visit order (:810-828);
+ *     an empty tree gives a valid empty set (:537-559)
+ *   - result items alias live tree nodes: a set is invalidated by kd_clear/kd_free
+ *   - kd_res_item3/kd_res_item3f test the pointee, not the pointer, and return NULL (:666-684)
+ * Documented differences:
+ *   - exact distance ties: the reference's winner depends on tree shape; this library
+ *     returns the LOWEST insertion index among fp64-equal minima
+ *   - only k == 3 is served by the device path; kd_create(k != 3) returns NULL
+ *   - every query needs a HIP device; there is no host fallback (queries return NULL and
+ *     print a diagnostic when the device is missing)
+ */
+#ifndef PCT_KDTREE_KDTREE_H
+#define PCT_KDTREE_KDTREE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+struct kdtree;   /* opaque */
+struct kdres;    /* opaque */
+
+/* lifecycle -- kdtree.c:112-164 */
+struct kdtree *kd_create(int k);
+void kd_free(struct kdtree *tree);
+void kd_clear(struct kdtree *tree);
+void kd_data_destructor(struct kdtree *tree, void (*destr)(void *));
+
+/* insertion, 0 on success / -1 on allocation failure -- kdtree.c:167-260 */
+int kd_insert(struct kdtree *tree, const double *pos, void *data);
+int kd_insertf(struct kdtree *tree, const float *pos, void *data);
+int kd_insert3(struct kdtree *tree, double x, double y, double z, void *data);
+int kd_insert3f(struct kdtree *tree, float x, float y, float z, void *data);
+
+/* exact nearest neighbour: result set of size 1, or NULL -- kdtree.c:345-509 */
+struct kdres *kd_nearest(struct kdtree *tree, const double *pos);
+struct kdres *kd_nearestf(struct kdtree *tree, const float *pos);
+struct kdres *kd_nearest3(struct kdtree *tree, double x, double y, double z);
+struct kdres *kd_nearest3f(struct kdtree *tree, float x, float y, float z);
+
+/* all nodes within `range` (inclusive) -- kdtree.c:262-293, 537-611 */
+struct kdres *kd_nearest_range(struct kdtree *tree, const double *pos, double range);
+struct kdres *kd_nearest_rangef(struct kdtree *tree, const float *pos, float range);
+struct kdres *kd_nearest_range3(struct kdtree *tree, double x, double y, double z, double range);
+struct kdres *kd_nearest_range3f(struct kdtree *tree, float x, float y, float z, float range);
+
+/* result-set cursor -- kdtree.c:613-689 */
+void kd_res_free(struct kdres *set);
+int kd_res_size(struct kdres *set);
+void kd_res_rewind(struct kdres *set);
+int kd_res_end(struct kdres *set);
+int kd_res_next(struct kdres *set);
+void *kd_res_item(struct kdres *set, double *pos);
+void *kd_res_itemf(struct kdres *set, float *pos);
+void *kd_res_item3(struct kdres *set, double *x, double *y, double *z);
+void *kd_res_item3f(struct kdres *set, float *x, float *y, float *z);
+void *kd_res_item_data(struct kdres *set);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCT_KDTREE_KDTREE_H */

@@ -1,0 +1,311 @@
+"""ctypes loader for the CHECKER libraries under oracle/.  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Nothing under pointcloudtraj_amd/ does.
+
+Two backends with one interface:
+  PortKD  -- oracle/liboracle.so, our CPU restatement (okd_* symbols)
+  RefKD   -- oracle/_ref/libkdtree_ref.so, the reference's own kdtree.c compiled unmodified,
+             driven through oracle/_ref/librefshim.so (our batch loops over its public API)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PORT = os.path.join(_HERE, "liboracle.so")
+_REF = os.path.join(_HERE, "_ref", "libkdtree_ref.so")
+_SHIM = os.path.join(_HERE, "_ref", "librefshim.so")
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def build(force: bool = False) -> None:
+    """Compile the checker (and, when /root/reference is present, oracle/_ref)."""
+    if force or not os.path.exists(_PORT) or os.path.exists("/root/reference/Utils/kdtree/src/kdtree.c"):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True, stdout=subprocess.DEVNULL)
+
+
+def have_ref() -> bool:
+    return os.path.exists(_REF) and os.path.exists(_SHIM)
+
+
+_port = None
+_ref = None
+_shim = None
+
+
+def port_lib():
+    global _port
+    if _port is None:
+        if not os.path.exists(_PORT):
+            build()
+        L = C.CDLL(_PORT)
+        L.okd_create.restype = C.c_void_p
+        L.okd_create.argtypes = [C.c_int]
+        L.okd_free.argtypes = [C.c_void_p]
+        L.okd_clear.argtypes = [C.c_void_p]
+        L.okd_insertf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64]
+        L.okd_nearestf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64, _i32p, _f64p]
+        L.okd_range_countf_batch.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int64, _i32p]
+        L.okd_brute_nearestf.argtypes = [_f32p, C.c_int64, _f32p, C.c_int64, _i32p, _f64p]
+        L.okd_brute_countf.argtypes = [_f32p, C.c_int64, _f32p, _f32p, C.c_int64, _i32p]
+        for n in ("okd_nearest_rangef",):
+            getattr(L, n).restype = C.c_void_p
+        L.okd_nearest_rangef.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float]
+        L.okd_nearestf.restype = C.c_void_p
+        L.okd_nearestf.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.okd_res_free.argtypes = [C.c_void_p]
+        L.okd_res_size.argtypes = [C.c_void_p]
+        L.okd_res_end.argtypes = [C.c_void_p]
+        L.okd_res_next.argtypes = [C.c_void_p]
+        L.okd_res_rewind.argtypes = [C.c_void_p]
+        L.okd_res_item_id.argtypes = [C.c_void_p]
+        L.okd_res_item_id.restype = C.c_int32
+        L.okd_res_item_data.argtypes = [C.c_void_p]
+        L.okd_res_item_data.restype = C.c_void_p
+        L.okd_res_item.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.okd_res_item.restype = C.c_void_p
+        L.okd_res_item3.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3
+        L.okd_res_item3.restype = C.c_void_p
+        L.okd_insert.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        L.okd_data_destructor.argtypes = [C.c_void_p, C.c_void_p]
+        # corridor port
+        L.ocor_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, _f64p, C.c_int64, _f64p, _i32p, _f64p, _u8p]
+        L.ocor_bezier_pos.argtypes = [_f64p, C.c_int, C.c_double, _f64p]
+        L.ocor_bezier_samples.restype = C.c_int64
+        L.ocor_bezier_samples.argtypes = [_f64p, C.c_int64, _f64p, _i32p, C.c_int32, C.c_double, C.c_double, C.c_double,
+                                          _i32p, _f64p, _f64p, C.c_int64]
+        L.ocor_check_safe_trajectory.restype = C.c_int64
+        L.ocor_check_safe_trajectory.argtypes = [C.c_void_p, C.c_void_p, _f64p, C.c_int64, _f64p, _i32p, C.c_int32,
+                                                 C.c_double, C.c_double, C.c_double, C.c_int64,
+                                                 C.POINTER(C.c_int64), _f64p, _f64p, _f64p, _i32p]
+        _port = L
+    return _port
+
+
+def ref_libs():
+    global _ref, _shim
+    if _ref is None:
+        if not have_ref():
+            raise FileNotFoundError("oracle/_ref is not built (needs /root/reference; run `make -C oracle`)")
+        R = C.CDLL(_REF)
+        R.kd_create.restype = C.c_void_p
+        R.kd_create.argtypes = [C.c_int]
+        R.kd_free.argtypes = [C.c_void_p]
+        R.kd_clear.argtypes = [C.c_void_p]
+        R.kd_nearestf.restype = C.c_void_p
+        R.kd_nearestf.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        R.kd_nearest_rangef.restype = C.c_void_p
+        R.kd_nearest_rangef.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float]
+        R.kd_res_free.argtypes = [C.c_void_p]
+        R.kd_res_size.argtypes = [C.c_void_p]
+        R.kd_res_item3.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 3
+        R.kd_res_item3.restype = C.c_void_p
+        R.kd_res_item_data.argtypes = [C.c_void_p]
+        R.kd_res_item_data.restype = C.c_void_p
+        R.kd_insert.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
+        R.kd_data_destructor.argtypes = [C.c_void_p, C.c_void_p]
+        S = C.CDLL(_SHIM)
+        S.refshim_insertf_batch.restype = C.c_int64
+        S.refshim_insertf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64, C.c_int64]
+        S.refshim_nearestf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64, _i32p, _f64p]
+        S.refshim_nearestf_timed.restype = C.c_double
+        S.refshim_nearestf_timed.argtypes = [C.c_void_p, _f32p, C.c_int64, _i32p]
+        S.refshim_rangef.restype = C.c_int64
+        S.refshim_rangef.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, _i32p, C.c_int64]
+        S.refshim_range_countf_batch.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int64, _i32p]
+        _ref, _shim = R, S
+    return _ref, _shim
+
+
+def _f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class PortKD:
+    """Our CPU restatement behind the same batch interface as RefKD."""
+
+    kind = "port"
+
+    def __init__(self):
+        self.L = port_lib()
+        self.h = self.L.okd_create(3)
+        self.n = 0
+
+    def close(self):
+        if self.h:
+            self.L.okd_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insert(self, xyz):
+        xyz = _f32c(xyz).reshape(-1, 3)
+        assert self.n == 0, "batch insert assigns ids from 0"
+        if self.L.okd_insertf_batch(self.h, xyz, len(xyz)):
+            raise MemoryError
+        self.n += len(xyz)
+
+    def nearest(self, q):
+        q = _f32c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        if self.L.okd_nearestf_batch(self.h, q, len(q), idx, d2):
+            raise RuntimeError("empty tree")
+        return idx, d2
+
+    def range_ids(self, q, r):
+        """ids in the reference's iteration order for one query."""
+        q = _f32c(q).reshape(3)
+        res = self.L.okd_nearest_rangef(self.h, q.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(r))
+        out = []
+        while not self.L.okd_res_end(res):
+            out.append(self.L.okd_res_item_id(res))
+            self.L.okd_res_next(res)
+        assert len(out) == self.L.okd_res_size(res)
+        self.L.okd_res_free(res)
+        return np.asarray(out, np.int32)
+
+    def range_count(self, q, r):
+        q = _f32c(q).reshape(-1, 3)
+        r = _f32c(np.broadcast_to(r, (len(q),)))
+        cnt = np.empty(len(q), np.int32)
+        if self.L.okd_range_countf_batch(self.h, q, r, len(q), cnt):
+            raise MemoryError
+        return cnt
+
+
+class RefKD:
+    """The reference's compiled kdtree.c."""
+
+    kind = "reference"
+
+    def __init__(self):
+        self.R, self.S = ref_libs()
+        self.h = self.R.kd_create(3)
+        self.n = 0
+
+    def close(self):
+        if self.h:
+            self.R.kd_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insert(self, xyz):
+        xyz = _f32c(xyz).reshape(-1, 3)
+        got = self.S.refshim_insertf_batch(self.h, xyz, len(xyz), self.n)
+        if got != len(xyz):
+            raise MemoryError
+        self.n += len(xyz)
+
+    def nearest(self, q):
+        q = _f32c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        d2 = np.empty(len(q), np.float64)
+        if self.S.refshim_nearestf_batch(self.h, q, len(q), idx, d2):
+            raise RuntimeError("empty tree")
+        return idx, d2
+
+    def nearest_timed(self, q):
+        q = _f32c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        return self.S.refshim_nearestf_timed(self.h, q, len(q), idx), idx
+
+    def range_ids(self, q, r):
+        q = _f32c(q).reshape(3)
+        cap = max(self.n, 1)
+        out = np.empty(cap, np.int32)
+        n = self.S.refshim_rangef(self.h, q.ctypes.data_as(C.POINTER(C.c_float)), C.c_float(r), out, cap)
+        if n < 0:
+            raise RuntimeError(f"refshim_rangef -> {n}")
+        return out[:n].copy()
+
+    def range_count(self, q, r):
+        q = _f32c(q).reshape(-1, 3)
+        r = _f32c(np.broadcast_to(r, (len(q),)))
+        cnt = np.empty(len(q), np.int32)
+        if self.S.refshim_range_countf_batch(self.h, q, r, len(q), cnt):
+            raise MemoryError
+        return cnt
+
+
+def brute_nearest(xyz, q):
+    """Exhaustive fp64 scan, lowest index wins ties (the engine's tie rule)."""
+    L = port_lib()
+    xyz = _f32c(xyz).reshape(-1, 3)
+    q = _f32c(q).reshape(-1, 3)
+    idx = np.empty(len(q), np.int32)
+    d2 = np.empty(len(q), np.float64)
+    L.okd_brute_nearestf(xyz, len(xyz), q, len(q), idx, d2)
+    return idx, d2
+
+
+def brute_count(xyz, q, r):
+    L = port_lib()
+    xyz = _f32c(xyz).reshape(-1, 3)
+    q = _f32c(q).reshape(-1, 3)
+    r = _f32c(np.broadcast_to(r, (len(q),)))
+    cnt = np.empty(len(q), np.int32)
+    L.okd_brute_countf(xyz, len(xyz), q, r, len(q), cnt)
+    return cnt
+
+
+class _CorParams(C.Structure):
+    _fields_ = [("start", C.c_double * 3), ("sample_range", C.c_double), ("search_margin", C.c_double),
+                ("max_radius", C.c_double), ("cloud_empty", C.c_int)]
+
+
+def corridor_params(start, sample_range, search_margin, max_radius, cloud_empty=False):
+    p = _CorParams()
+    p.start[:] = [float(v) for v in start]
+    p.sample_range, p.search_margin, p.max_radius = float(sample_range), float(search_margin), float(max_radius)
+    p.cloud_empty = int(bool(cloud_empty))
+    return p
+
+
+def inflate(kd: PortKD, params, pts):
+    """ocor_inflate_batch: radii (f64), NN idx, d2, collide flags for (n,3) f64 points."""
+    L = port_lib()
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    n = len(pts)
+    rad = np.empty(n, np.float64)
+    idx = np.empty(n, np.int32)
+    d2 = np.empty(n, np.float64)
+    col = np.empty(n, np.uint8)
+    L.ocor_inflate_batch(C.byref(params), kd.h, pts, n, rad, idx, d2, col)
+    return rad, idx, d2, col
+
+
+def bezier_pos(coef_row, order, u):
+    L = port_lib()
+    out = np.empty(3, np.float64)
+    L.ocor_bezier_pos(np.ascontiguousarray(coef_row, np.float64), int(order), float(u), out)
+    return out
+
+
+def check_safe_trajectory(kd: PortKD, params, polycoef, seg_time, orders, t_start, stop_time, dt=0.02, cap=4096):
+    """Returns dict(first_hit, n, pos, radius, d2, idx) following checkSafeTrajectory."""
+    L = port_lib()
+    polycoef = np.ascontiguousarray(polycoef, np.float64)
+    seg_time = np.ascontiguousarray(seg_time, np.float64)
+    orders = np.ascontiguousarray(orders, np.int32)
+    nseg = len(seg_time)
+    pos = np.zeros((cap, 3), np.float64)
+    rad = np.zeros(cap, np.float64)
+    d2 = np.zeros(cap, np.float64)
+    idx = np.zeros(cap, np.int32)
+    ns = C.c_int64(0)
+    first = L.ocor_check_safe_trajectory(C.byref(params), kd.h, polycoef, polycoef.shape[1], seg_time, orders, nseg,
+                                         float(t_start), float(stop_time), float(dt), cap, C.byref(ns),
+                                         pos.reshape(-1), rad, d2, idx)
+    n = ns.value
+    return dict(first_hit=int(first), n=int(n), pos=pos[:n], radius=rad[:n], d2=d2[:n], idx=idx[:n])

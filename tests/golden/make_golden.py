@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+Run in the BUILD CONTAINER (needs /root/reference to compile oracle/_ref):
+    python tests/golden/make_golden.py
+
+What is recorded, and from which implementation:
+  kd_nn_*.npz, kd_range_*.npz, kd_api_edges.npz
+      outputs of the REFERENCE's own Utils/kdtree/src/kdtree.c (compiled unmodified into
+      oracle/_ref/libkdtree_ref.so) driven through its public kd_* API.  These pin the
+      oracle port (tests/test_oracle_golden.py) and, on the GPU, the HIP path.
+  inflate_c1.npz, bezier_check.npz
+      outputs of oracle/corridor_port.c (planner arithmetic: parity UNPINNED, see that
+      file's header) on top of the pinned NN.  Every NN inside them is cross-checked
+      against the reference library at generation time.
+
+Inputs are either stored in the fixture (small clouds) or regenerated from
+pointcloudtraj_amd.synth seeds recorded in the fixture (large clouds).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from pointcloudtraj_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def save(name, **kw):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **kw)
+    print(f"  wrote {name}: " + ", ".join(f"{k}{getattr(v, 'shape', '')}" for k, v in kw.items()))
+
+
+def tie_mask(pts, q, d2_ref):
+    """queries whose minimal fp64 d2 is attained by more than one point."""
+    out = np.zeros(len(q), bool)
+    P = pts.astype(np.float64)
+    for i, qq in enumerate(q.astype(np.float64)):
+        dx, dy, dz = P[:, 0] - qq[0], P[:, 1] - qq[1], P[:, 2] - qq[2]
+        s = dx * dx
+        s = s + dy * dy
+        s = s + dz * dz
+        out[i] = (s == d2_ref[i]).sum() > 1
+    return out
+
+
+def nn_case(name, pts, q, store_points=True, **meta):
+    R = O.RefKD()
+    R.insert(pts)
+    idx, d2 = R.nearest(q)
+    bi, bd = O.brute_nearest(pts, q)
+    assert np.array_equal(bd, d2), "reference d2 must equal exhaustive fp64 minimum"
+    ties = (bi != idx)
+    if len(pts) <= 20000:
+        tm = tie_mask(pts, q, d2)
+        assert not (ties & ~tm).any()
+        ties = tm
+    kw = dict(queries=q, ref_idx=idx, ref_d2=d2, lowest_idx=bi, tie=ties.astype(np.uint8))
+    if store_points:
+        kw["points"] = pts
+    for k, v in meta.items():
+        kw[k] = np.asarray(v)
+    save(name, **kw)
+    R.close()
+
+
+def gen_nn():
+    print("NN fixtures (reference kdtree.c):")
+    # tiny trees: N = 1, 2, 17
+    for n in (1, 2, 17):
+        pts = synth.uniform_points(100 + n, n, 0, 10)
+        q = synth.uniform_points(200 + n, 64, -2, 12)
+        nn_case(f"kd_nn_n{n}.npz", pts, q)
+    # N = 1000 uniform, shuffled insert
+    pts = synth.uniform_points(101, 1000, 0, 100)
+    q = synth.uniform_points(201, 512, -5, 105)
+    nn_case("kd_nn_n1000.npz", pts, q)
+    # N = 1e5 uniform (inputs regenerated from seeds; insertion order = generation order)
+    pts = synth.uniform_points(1, 100000, 0, 100)
+    q = synth.uniform_points(2, 4096, 0, 100)
+    nn_case("kd_nn_n100000.npz", pts, q, store_points=False, cloud_seed=1, cloud_n=100000, lo=0.0, hi=100.0,
+            query_seed=2)
+    # clustered, grid-aligned (tie-rich)
+    pts = synth.clustered_points(3, 20000, 0, 30)
+    q = synth.uniform_points(4, 1024, 0, 30)
+    nn_case("kd_nn_clustered.npz", pts, q)
+    # config C1: pillar map cropped to 5 m around the start pose, shuffled insertion
+    full = synth.pillar_map()
+    crop = synth.crop_ball(full, (-10, -10, 2), 5.0)
+    crop = crop[synth.shuffled_order(7, len(crop))]
+    q = (np.float32([-10, -10, 2]) + (synth.uniform_points(5, 1024, -1, 1) * np.float32(5.0))).astype(np.float32)
+    nn_case("kd_nn_c1_crop5m.npz", crop, q, map_points_total=len(full))
+    # duplicates: every point inserted twice
+    base = synth.uniform_points(102, 300, 0, 10)
+    pts = np.concatenate([base, base])
+    q = synth.uniform_points(202, 128, 0, 10)
+    nn_case("kd_nn_duplicates.npz", pts, q)
+
+
+def gen_range():
+    print("range fixtures (reference kdtree.c, ids in ITERATION order):")
+    R = O.RefKD()
+    pts = synth.uniform_points(103, 1000, 0, 20)
+    R.insert(pts)
+    q = synth.uniform_points(203, 96, 0, 20)
+    radii = (np.float32(0.25) + synth.uniform01_f32(303, 96) * np.float32(4.0)).astype(np.float32)
+    ids, offs = [], [0]
+    for i in range(len(q)):
+        a = R.range_ids(q[i], float(radii[i]))
+        ids.append(a)
+        offs.append(offs[-1] + len(a))
+    save("kd_range_n1000.npz", points=pts, queries=q, radii=radii, ids=np.concatenate(ids).astype(np.int32),
+         offsets=np.asarray(offs, np.int64))
+    R.close()
+
+    # integer lattice: distances exactly equal to the range, and |dx| == range on split planes
+    R = O.RefKD()
+    g = np.arange(0, 7, dtype=np.float32)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pts = pts[synth.shuffled_order(9, len(pts))]
+    R.insert(pts)
+    q = np.float32([[3, 3, 3], [0, 0, 0], [3, 3, 1], [6, 6, 6], [2, 3, 4], [3.5, 3.5, 3.5], [1, 5, 2], [4, 0, 6]])
+    radii = np.float32([2, 3, 1, 5, 2, 1.5, 3, 4])
+    ids, offs = [], [0]
+    brute = []
+    for i in range(len(q)):
+        a = R.range_ids(q[i], float(radii[i]))
+        ids.append(a)
+        offs.append(offs[-1] + len(a))
+        brute.append(int(O.brute_count(pts, q[i:i + 1], float(radii[i]))[0]))
+    save("kd_range_lattice.npz", points=pts, queries=q, radii=radii, ids=np.concatenate(ids).astype(np.int32),
+         offsets=np.asarray(offs, np.int64), inclusive_brute_count=np.asarray(brute, np.int32))
+    R.close()
+
+    # C1 crop, the radii treeRewire uses (2 * node radius, float)
+    R = O.RefKD()
+    full = synth.pillar_map()
+    crop = synth.crop_ball(full, (-10, -10, 2), 5.0)
+    crop = crop[synth.shuffled_order(7, len(crop))]
+    R.insert(crop)
+    q = (np.float32([-10, -10, 2]) + (synth.uniform_points(6, 48, -1, 1) * np.float32(4.0))).astype(np.float32)
+    radii = (np.float32(0.3) + synth.uniform01_f32(306, 48) * np.float32(1.2)).astype(np.float32)
+    ids, offs = [], [0]
+    for i in range(len(q)):
+        a = R.range_ids(q[i], float(radii[i]))
+        ids.append(a)
+        offs.append(offs[-1] + len(a))
+    save("kd_range_c1_crop5m.npz", points=crop, queries=q, radii=radii, ids=np.concatenate(ids).astype(np.int32),
+         offsets=np.asarray(offs, np.int64))
+    R.close()
+
+
+def gen_api_edges():
+    print("API edge cases (reference kdtree.c):")
+    R, S = O.ref_libs()
+    t = R.kd_create(3)
+    q = (C.c_float * 3)(1, 2, 3)
+    nn_empty_is_null = int(R.kd_nearestf(t, q) is None)
+    rs = R.kd_nearest_rangef(t, q, C.c_float(5.0))
+    range_empty_valid = int(rs is not None)
+    range_empty_size = R.kd_res_size(rs)
+    R.kd_res_free(rs)
+
+    # payload destructor order on kd_clear
+    order = []
+    CB = C.CFUNCTYPE(None, C.c_void_p)
+    cb = CB(lambda p: order.append(int(p or 0)))
+    R.kd_data_destructor(t, C.cast(cb, C.c_void_p))
+    pts = np.float64([[5, 5, 5], [2, 6, 1], [8, 1, 9], [1, 1, 1], [3, 9, 4], [7, 7, 7], [9, 0, 2], [5, 5, 5]])
+    for i, p in enumerate(pts):
+        R.kd_insert(t, p.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(i + 1))
+    # kd_res_item3 quirk
+    q2 = (C.c_float * 3)(2.2, 6.1, 1.3)
+    rs = R.kd_nearestf(t, q2)
+    x, y, z = C.c_double(0.0), C.c_double(123.0), C.c_double(-1.0)
+    ret = R.kd_res_item3(rs, C.byref(x), C.byref(y), C.byref(z))
+    item3_ret_null = int(ret is None)
+    item3_xyz = np.float64([x.value, y.value, z.value])
+    nn_payload = int(R.kd_res_item_data(rs) or 0)
+    R.kd_res_free(rs)
+    R.kd_clear(t)
+    after_clear_nn_null = int(R.kd_nearestf(t, q) is None)
+    R.kd_free(t)
+    save("kd_api_edges.npz", nn_empty_is_null=np.int32(nn_empty_is_null), range_empty_valid=np.int32(range_empty_valid),
+         range_empty_size=np.int32(range_empty_size), destructor_points=pts,
+         destructor_order=np.asarray(order, np.int32), item3_query=np.float32([2.2, 6.1, 1.3]),
+         item3_in=np.float64([0.0, 123.0, -1.0]), item3_out=item3_xyz, item3_ret_null=np.int32(item3_ret_null),
+         item3_nn_payload=np.int32(nn_payload), after_clear_nn_null=np.int32(after_clear_nn_null))
+
+
+# clean_demo.launch constants (Planner/launch/clean_demo.launch:23-58)
+C1 = dict(start=(-10.0, -10.0, 2.0), sample_range=30.0, search_margin=0.25, max_radius=1.5)
+
+
+def gen_inflate():
+    print("inflation fixture (corridor_port.c over the pinned NN; planner arithmetic unpinned):")
+    full = synth.pillar_map()
+    crop = synth.crop_ball(full, (-10, -10, 2), 5.0)
+    crop = crop[synth.shuffled_order(7, len(crop))]
+    P = O.PortKD()
+    P.insert(crop)
+    R = O.RefKD()
+    R.insert(crop)
+    u = synth.splitmix64(21, 3 * 600)
+    pts = ((u >> np.uint64(11)).astype(np.float64) * 2.0 ** -53).reshape(-1, 3)
+    pts = np.float64([-10, -10, 2]) + (pts * 2 - 1) * np.float64([6.0, 6.0, 2.0])
+    # a few far points that take the early-out (sample_range + max_radius)
+    pts[-4:] = np.float64([[25, 25, 2], [-10, -10, 40], [21.6, -10, 2], [-10, 21.4, 2]])
+    prm = O.corridor_params(**C1)
+    rad, idx, d2, col = O.inflate(P, prm, pts)
+    near = idx >= 0
+    ir, dr = R.nearest(pts[near].astype(np.float32))
+    assert np.array_equal(ir, idx[near]) and np.array_equal(dr, d2[near])
+    # the unclamped variant of config C3
+    prm2 = O.corridor_params(C1["start"], C1["sample_range"], C1["search_margin"], 1e9)
+    rad2, _, _, _ = O.inflate(P, prm2, pts)
+    bi, _ = O.brute_nearest(crop, pts.astype(np.float32))
+    save("inflate_c1.npz", points=crop, queries=pts, start=np.float64(C1["start"]), sample_range=np.float64(30.0),
+         search_margin=np.float64(0.25), max_radius=np.float64(1.5), radius=rad, nn_idx=idx, nn_d2=d2,
+         collide=col, radius_unclamped=rad2, lowest_idx=np.where(near, bi, -1).astype(np.int32))
+    P.close()
+    R.close()
+
+
+def gen_bezier():
+    print("Bezier collision-check fixture (corridor_port.c; planner arithmetic unpinned):")
+    full = synth.pillar_map()
+    crop = synth.crop_ball(full, (-10, -10, 2), 8.0)
+    crop = crop[synth.shuffled_order(8, len(crop))]
+    P = O.PortKD()
+    P.insert(crop)
+    prm = O.corridor_params(**C1)
+    orders = np.int32([6, 4, 8])
+    seg_time = np.float64([1.3, 0.9, 1.7])
+    maxo = int(orders.max())
+
+    def make_coef(seed, waypoints):
+        """control points interpolating consecutive waypoints with interior jitter; stored
+        PRE-divided by the segment time, as the optimizer's scaled variables are
+        (sim_planning_demo.cpp:752-753)"""
+        coef = np.zeros((3, 3 * (maxo + 1)))
+        rng = (synth.splitmix64(seed, 200) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        k = 0
+        for s in range(3):
+            n = int(orders[s])
+            m = n + 1
+            p0, p1 = waypoints[s], waypoints[s + 1]
+            for d in range(3):
+                for j in range(m):
+                    w = j / n
+                    jitter = (rng[k] - 0.5) * 0.4 if 0 < j < n else 0.0
+                    k += 1
+                    coef[s, d * m + j] = ((1 - w) * p0[d] + w * p1[d] + jitter) / seg_time[s]
+        return coef
+
+    p0 = np.float64([-10, -10, 2])
+    clear_wp = [p0 + np.float64([2.2, 1.9, 0.1]) * i for i in range(4)]
+    coef = make_coef(31, clear_wp)
+    # a trajectory aimed straight through the obstacle point nearest to 5 m ahead of the start
+    c64 = crop.astype(np.float64)
+    ahead = p0 + np.float64([3.0, 3.0, 0.0])
+    tgt = c64[np.argmin(((c64 - ahead) ** 2).sum(1))]
+    hit_wp = [p0, p0 + (tgt - p0) * 0.6, tgt + (tgt - p0) * 0.1, tgt + (tgt - p0) * 0.8]
+    coef_hit = make_coef(32, hit_wp)
+    cases = []
+    for cf, t_start, stop in ((coef, 0.0, 2.0), (coef, 0.37, 2.0), (coef, 1.5, 0.5), (coef, 2.9, 2.0), (coef, 0.0, 10.0),
+                              (coef_hit, 0.0, 2.0), (coef_hit, 0.9, 2.0), (coef_hit, 0.0, 0.5), (coef_hit, 2.5, 2.0)):
+        r = O.check_safe_trajectory(P, prm, cf, seg_time, orders, t_start, stop)
+        cases.append((cf, t_start, stop, r))
+    # per-evaluation known answers for getPosFromBezier
+    us = np.float64([0.0, 0.1, 0.25, 0.5, 0.77, 1.0])
+    pos = np.stack([np.stack([O.bezier_pos(coef[s], int(orders[s]), u) for u in us]) for s in range(3)])
+    kw = dict(points=crop, polycoef=coef, seg_time=seg_time, orders=orders, eval_u=us, eval_pos=pos,
+              start=np.float64(C1["start"]), sample_range=np.float64(30.0), search_margin=np.float64(0.25),
+              max_radius=np.float64(1.5), n_cases=np.int32(len(cases)))
+    for i, (cf, ts, st, r) in enumerate(cases):
+        kw[f"case{i}_polycoef"] = cf
+        kw[f"case{i}_t_start"] = np.float64(ts)
+        kw[f"case{i}_stop_time"] = np.float64(st)
+        kw[f"case{i}_first_hit"] = np.int64(r["first_hit"])
+        kw[f"case{i}_pos"] = r["pos"]
+        kw[f"case{i}_radius"] = r["radius"]
+        kw[f"case{i}_d2"] = r["d2"]
+        kw[f"case{i}_idx"] = r["idx"]
+        print(f"    case{i}: t_start={ts} stop={st} samples={r['n']} first_hit={r['first_hit']}")
+    save("bezier_check.npz", **kw)
+    P.close()
+
+
+if __name__ == "__main__":
+    O.build(force=True)
+    assert O.have_ref(), "needs /root/reference to build oracle/_ref"
+    gen_nn()
+    gen_range()
+    gen_api_edges()
+    gen_inflate()
+    gen_bezier()
