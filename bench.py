@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- NN queries/s of the obstacle-cloud engine on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic queries: the batched 1-NN
+(pct_nn_batch_dev, include/pct_engine.h) of Q queries against the cloud resident in HBM.
+Workload at N=1 (config C3-throughput of SURVEY.md section 8(d)): 10,000,000 uniform points in
+[0,100)^3 (seed 3), Q = 1,048,576 uniform queries (seed 5), cell-pruned kernel.
+At N>1 (weak scaling): the cloud grows to N x 10M points at constant
+density, rank r owns the contiguous index range [r*10M, (r+1)*10M) in its own HBM, the query
+batch is replicated, every rank runs the same kernel on its shard and ONE exchange step
+(RCCL all_reduce(min) on fp64 d2, then all_reduce(min) on the matching indices) merges them.
+
+Reported `value` = ranks x Q / t: (query, 10M-point shard) evaluations per second, i.e. queries/s
+in units of the metric's 10M-point cloud; `config.answered_queries_per_s` = Q / t is the rate of
+merged answers against the whole N x 10M cloud.  At N=1 both are the same number.
+
+One JSON line on rank 0; see the field notes in DESIGN.md section 6.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--queries", type=int, default=1 << 20)
+    ap.add_argument("--algo", choices=["grid", "stream"], default="grid")
+    ap.add_argument("--cell", type=float, default=0.0, help="grid cell size (<=0: automatic)")
+    ap.add_argument("--cpu-queries", type=int, default=20000, help="queries timed on the host kd-tree (0 = skip)")
+    ap.add_argument("--cpu-points", type=int, default=0, help="points in the host kd-tree (0 = same as --points)")
+    ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming kernel at Q=8 (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(points_fn, n_points, queries, nq):
+    """The reference's own kdtree.c (oracle/_ref, kind 'reference') or, when that library did not
+    travel, our port of it (kind 'port'); one host thread, the loop the reference's callers run
+    (kd_nearestf -> kd_res_item_data -> kd_res_free, corridor_finder.cpp:428-437)."""
+    from oracle import oracle as O
+    O.build()
+    kd = O.RefKD() if O.have_ref() else O.PortKD()
+    from pointcloudtraj_amd import synth
+    order = synth.shuffled_order(1234, n_points)       # shuffled insertion, as the survey's calibration did
+    t0 = time.perf_counter()
+    pts = points_fn()
+    kd.insert(pts[order])
+    t_build = time.perf_counter() - t0
+    q = np.ascontiguousarray(queries[:nq])
+    if hasattr(kd, "nearest_timed"):
+        secs, idx = kd.nearest_timed(q)
+    else:
+        t0 = time.perf_counter()
+        idx, _ = kd.nearest(q)
+        secs = time.perf_counter() - t0
+    out = {"value": nq / secs, "unit": "queries/s", "cores": 1, "kind": kd.kind,
+           "sample": f"{nq} of the batch's queries against a host kd-tree of {n_points} points "
+                     f"(shuffled kd_insertf build {t_build:.1f} s, not included)",
+           "build_s": round(t_build, 2)}
+    return out, order[idx.astype(np.int64)], q
+
+
+def main():
+    a = parse()
+    import torch   # before the engine: one HIP runtime per process (engine._preload_hip_runtime)
+    from pointcloudtraj_amd import dist as D, engine as E, synth
+    import torch.distributed as tdist
+
+    rank, local, world = D.init_process_group_from_env()
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    dev = local if world > 1 else 0
+    n_total = a.points * world
+    side = 100.0 * (world ** (1.0 / 3.0))      # constant density as the cloud grows
+    Q = a.queries
+    algo = E.ALGO_GRID if a.algo == "grid" else E.ALGO_STREAM
+
+    sc = D.ShardedCloud(n_total, rank, world, dev)
+    local_pts = synth.uniform_points(3, sc.end - sc.begin, 0.0, side, offset=sc.begin)
+    sc.set_input_local(local_pts)
+    t0 = time.perf_counter()
+    if algo == E.ALGO_GRID:
+        sc.build_grid(a.cell)
+    E.sync()
+    t_grid = time.perf_counter() - t0
+    q_host = synth.uniform_points(5, Q, 0.0, side)
+    sc.reserve(Q)
+    q = torch.from_numpy(q_host).to(sc.device)
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    kern_ms = []
+    for _ in range(a.warmup):
+        sc.nn(q, algo)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        d2, idx = sc.nn(q, algo)
+        # (event timestamps are read back after the timed region)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=sc.device)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / a.steps
+
+    # kernel time from HIP events on the launch stream, averaged over extra untimed passes
+    for _ in range(max(3, min(a.steps, 10))):
+        sc.nn_local(q, algo)
+        kern_ms.append(sc.cloud.last_kernel_ms())
+    k_ms = float(np.mean(kern_ms))
+    # algorithmic work of one launch (separate instrumented pass)
+    sc.cloud.set_work_counters(True)
+    sc.nn_local(q, algo)
+    torch.cuda.synchronize()
+    pts_scanned, runs = sc.cloud.last_work()
+    sc.cloud.set_work_counters(False)
+    bytes_alg = 16 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else 12 * len(local_pts) * ((Q + 7) // 8) + 24 * Q
+    achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            tdist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "nn_queries_per_sec_10M_point_cloud",
+        "value": world * Q / elapsed * a.steps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3-throughput: {a.points} uniform fp32 points per GPU in [0,{side:.1f})^3 (seed 3), "
+                        f"{Q} uniform NN queries per step (seed 5), {a.algo} kernel, inputs resident in HBM",
+            "points_per_gpu": a.points, "total_points": n_total, "queries_per_step": Q, "algo": a.algo,
+            "answered_queries_per_s": Q / elapsed * a.steps,
+            "parallelism": f"cloud sharded by contiguous index range over {world} GPU(s), queries replicated, "
+                           "all_reduce(min) merge" if world > 1 else "single GPU",
+            "grid": sc.cloud.grid_info() if sc.cloud.has_grid else None,
+            "grid_build_s": round(t_grid, 4),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "nn_grid_kernel" if algo == E.ALGO_GRID else "nn_stream_kernel<8>",
+            "kernel_ms": k_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
+            "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
+        },
+    }
+
+    # streaming kernel at its HBM-bound operating point (Q = 8 per pass), same cloud
+    if a.stream_probe and world == 1:
+        q8 = q[:8].contiguous()
+        for _ in range(3):
+            sc.cloud.nn_device(q8.data_ptr(), 8, sc._idx32.data_ptr(), sc._d2.data_ptr(), torch.cuda.current_stream().cuda_stream, E.ALGO_STREAM)
+        ms = []
+        for _ in range(20):
+            sc.cloud.nn_device(q8.data_ptr(), 8, sc._idx32.data_ptr(), sc._d2.data_ptr(), torch.cuda.current_stream().cuda_stream, E.ALGO_STREAM)
+            ms.append(sc.cloud.last_kernel_ms())
+        sms = float(np.median(ms))
+        sb = 12 * len(local_pts) + 24 * 8
+        out["stream_probe"] = {"kernel": "nn_stream_kernel<8> + reduce", "queries": 8, "kernel_ms": sms,
+                               "algorithmic_bytes": sb, "achieved_GBs": sb / (sms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "pair_evals_per_s": 8 * len(local_pts) / (sms * 1e-3)}
+
+    if a.cpu_queries > 0 and world == 1:
+        ncpu = a.cpu_points or a.points
+        base, cpu_idx, cq = cpu_baseline(lambda: local_pts[:ncpu], ncpu, q_host, min(a.cpu_queries, Q))
+        out["cpu_baseline"] = base
+        if ncpu == a.points:     # same cloud: the GPU answers must equal the host kd-tree's (parity in the bench run itself)
+            gi = idx[:len(cq)].cpu().numpy()
+            out["cpu_baseline"]["gpu_matches_cpu_indices"] = bool(np.array_equal(gi, cpu_idx))
+    print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

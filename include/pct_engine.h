@@ -1,0 +1,155 @@
+/*
+ * pct_engine.h -- C ABI of the MI355X obstacle-cloud engine (libpct_engine.so).
+ *
+ * This is the batched extension SURVEY.md section 8(b) specifies next to the 22 kd_* functions
+ * (include/kdtree/kdtree.h): an opaque cloud handle in HBM plus batch queries that replace
+ * the per-point PCL/FLANN calls on the planner's hot path.  Plain pointers and sizes only;
+ * int status codes; no exceptions cross the boundary; host buffers are caller-owned.
+ *
+ * Reference interface each entry point replaces (paths relative to /root/reference/):
+ *   pct_cloud_upload_*      safeRegionRrtStar::setInput           Planner/src/corridor_finder.cpp:93-99
+ *                           (rcvPointCloudCallBack                Planner/src/sim_planning_demo.cpp:159-167)
+ *   pct_nn_batch            kdtreeForMap.nearestKSearch(p,1,..)   Planner/src/corridor_finder.cpp:130
+ *                           with kd_nearestf arithmetic           Utils/kdtree/src/kdtree.c:345-491
+ *   pct_radius_count_batch  kd_nearest_rangef + kd_res_size       Utils/kdtree/src/kdtree.c:262-293,561-593,620-623
+ *   pct_inflate_batch       safeRegionRrtStar::radiusSearch       Planner/src/corridor_finder.cpp:113-133
+ *                           (+ checkRadius :656-659, checkTrajPtCol :412-416), batched over the loops at
+ *                           :829-835 (SafeRegionEvaluate) and :958-974 (treeRepair)
+ *   pct_bezier_check        checkSafeTrajectory/getPosFromBezier  Planner/src/sim_planning_demo.cpp:715-781
+ *
+ * Arithmetic contract (what "parity" means): coordinates are fp32 in HBM; every distance is
+ * computed in fp64 from the float-widened operands as ((dx*dx + dy*dy) + dz*dz) with one
+ * rounding per operation and no fused multiply-add -- bit-identical to kdtree.c:379-382.
+ * Nearest neighbour: the minimum of that value; among fp64-equal minima the LOWEST index
+ * wins (the reference's winner on exact ties depends on tree shape).  Radius count:
+ * d2 <= (double)r * (double)r, inclusive (kdtree.c:273).
+ *
+ * All entry points need a HIP device; there is no host fallback.
+ */
+#ifndef PCT_ENGINE_H
+#define PCT_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pct_cloud pct_cloud;     /* opaque: an obstacle cloud resident in HBM */
+typedef struct pct_plan pct_plan;       /* opaque: a hipGraph-captured fixed-shape query batch */
+
+enum pct_status {
+    PCT_OK = 0,
+    PCT_ERR_NO_DEVICE = 1,   /* no HIP device / runtime failure at init */
+    PCT_ERR_INVALID = 2,     /* bad argument */
+    PCT_ERR_ALLOC = 3,       /* host or device allocation failed */
+    PCT_ERR_HIP = 4,         /* a HIP call failed; see pct_last_error() */
+    PCT_ERR_EMPTY = 5,       /* query against an empty cloud (outputs are still filled: idx=PCT_NO_INDEX, d2=+inf) */
+    PCT_ERR_CAPACITY = 6     /* more points than the cloud's capacity */
+};
+
+#define PCT_NO_INDEX 0xFFFFFFFFu
+
+enum pct_algo {
+    PCT_ALGO_AUTO = 0,       /* grid kernel when a grid is built, streaming kernel otherwise */
+    PCT_ALGO_STREAM = 1,     /* brute-force SoA streaming kernel (no index needed; rolling clouds) */
+    PCT_ALGO_GRID = 2        /* cell-pruned kernel (needs pct_cloud_build_grid) */
+};
+
+/* ---- process / device ---------------------------------------------------------------- */
+int pct_init(int device);                       /* select the HIP device for this process */
+const char *pct_last_error(void);               /* thread-local text of the last failure */
+int pct_device_count(void);
+int pct_sync(void);                             /* wait for everything queued by this library */
+
+/* ---- cloud lifecycle ----------------------------------------------------------------- */
+int pct_cloud_create(int64_t capacity, pct_cloud **out);
+int pct_cloud_destroy(pct_cloud *c);
+int64_t pct_cloud_size(const pct_cloud *c);
+int64_t pct_cloud_capacity(const pct_cloud *c);
+/* index reported for local point i is base + i (multi-GPU shards; default 0) */
+int pct_cloud_set_index_base(pct_cloud *c, int64_t base);
+
+/* Replace the cloud.  `pts` is array-of-structures: x,y,z fp32 at byte offsets 0,4,8 of
+ * each `stride_bytes` record (12 = packed, 16 = pcl::PointXYZ).  De-interleaved to SoA on
+ * the device.  Drops any grid. */
+int pct_cloud_upload_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes);
+/* Same, from three device arrays (already SoA, e.g. produced on the GPU). */
+int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n);
+/* Rolling map: append n points, overwriting the oldest once capacity is reached (ring).
+ * Index of a point = its slot in the ring.  Drops any grid. */
+int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes);
+
+/* Build / drop the uniform-cell index used by PCT_ALGO_GRID.  cell_size <= 0 picks one from
+ * the bounding box and point count (about `pct` points per cell). */
+int pct_cloud_build_grid(pct_cloud *c, float cell_size);
+int pct_cloud_drop_grid(pct_cloud *c);
+int pct_cloud_has_grid(const pct_cloud *c);
+/* grid facts for tests/bench: dims[3], cell size, origin[3], number of cells */
+int pct_cloud_grid_info(const pct_cloud *c, int32_t dims[3], float *cell_size, float origin[3], int64_t *ncells);
+
+/* ---- batch queries, host buffers, synchronous ------------------------------------------ */
+/* q: Q x 3 fp32.  idx[Q] (index_base + local index), d2[Q] fp64. */
+int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double *d2);
+int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_t *idx, double *d2);
+/* count[Q] = #points with d2 <= r*r */
+int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t Q, uint32_t *count);
+int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const float *r, int64_t Q, uint32_t *count);
+/* lidar-style crop (camera_sensor.cpp:133-145): indices of all points within r of ONE centre,
+ * ascending index order; returns the count through *n_out (may exceed cap; only cap written). */
+int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+
+typedef struct pct_inflate_params {
+    double start[3];        /* start_pt */
+    double sample_range;    /* early-out: |p - start| > sample_range + max_radius */
+    double search_margin;
+    double max_radius;
+} pct_inflate_params;
+
+/* pts: Q x 3 fp64 (the planner's Vector3d).  radius[Q] as radiusSearch returns it;
+ * idx/d2 (optional, may be NULL) = NN, or PCT_NO_INDEX / +inf where the early-out fired. */
+int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *pts, int64_t Q,
+                      double *radius, uint32_t *idx, double *d2);
+
+typedef struct pct_bezier_traj {
+    const double *polycoef;   /* nseg rows of row_stride doubles: [x_0..x_n, y_0..y_n, z_0..z_n], n = orders[seg] */
+    int64_t row_stride;       /* 3 * (max_order + 1) */
+    const double *seg_time;   /* nseg */
+    const int32_t *orders;    /* nseg, each <= 12 */
+    int32_t nseg;
+} pct_bezier_traj;
+
+/* Sample the trajectory every dt from t_start over stop_time (reference loop semantics),
+ * inflate every sample, report the first one with negative radius (NN distance <
+ * search_margin).  first_hit = -1 when none.  Optional per-sample outputs (capacity cap):
+ * pos (cap x 3 fp64), radius, d2, idx. */
+int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflate_params *p,
+                     double t_start, double stop_time, double dt,
+                     int64_t *first_hit, int64_t *nsamples,
+                     int64_t cap, double *pos, double *radius, double *d2, uint32_t *idx);
+
+/* ---- batch queries, DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = the
+ * library's own stream).  For torch.distributed sharding and graph capture.  An empty
+ * shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ------------------------------------ */
+int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
+int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream);
+/* make sure workspaces for batches up to Q exist (call before capturing a graph) */
+int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q);
+
+/* ---- hipGraph-captured fixed-shape batch (config C5: 20 Hz replan) ----------------------- */
+/* Captures H2D(queries) -> NN kernels -> D2H(idx,d2) once; pct_plan_run replays it. */
+int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out);
+int pct_plan_run(pct_plan *p, const float *q, uint32_t *idx, double *d2);
+int pct_plan_destroy(pct_plan *p);
+
+/* ---- measurement hooks (bench.py): time of the last query batch's kernels on the stream
+ * they ran on, from HIP events recorded around them ---------------------------------------- */
+int pct_last_kernel_ms(pct_cloud *c, float *ms);
+/* algorithmic work of the last batch: points examined (sum over queries), cells examined */
+int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
+int pct_set_work_counters(pct_cloud *c, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCT_ENGINE_H */

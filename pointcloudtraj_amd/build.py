@@ -1,0 +1,51 @@
+"""In-tree build of the HIP libraries for gfx950 (hipcc cross-compiles without a GPU).
+
+Products (git-ignored, but they travel to the GPU box with the gpurun snapshot):
+    pointcloudtraj_amd/lib/libpct_engine.so   kernels + batched C ABI (include/pct_engine.h)
+    pointcloudtraj_amd/lib/libkdtree.so       drop-in kd_* ABI (include/kdtree/kdtree.h) over the engine
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "lib")
+ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
+KDTREE_SO = os.path.join(LIB, "libkdtree.so")
+
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+COMMON = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+          "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    os.makedirs(LIB, exist_ok=True)
+    hdrs = [os.path.join(ROOT, "include", "pct_engine.h"), os.path.join(ROOT, "include", "kdtree", "kdtree.h")]
+    eng_src = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hpp")]
+    if force or _stale(ENGINE_SO, eng_src + hdrs):
+        cmd = [HIPCC, *COMMON, "-o", ENGINE_SO, eng_src[0]]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    kd_src = [os.path.join(CSRC, "kdtree_gpu.cpp")]
+    if os.path.exists(kd_src[0]) and (force or _stale(KDTREE_SO, kd_src + hdrs + [ENGINE_SO])):
+        cmd = [HIPCC, *COMMON, "-x", "hip", "-o", KDTREE_SO, kd_src[0], "-L" + LIB, "-lpct_engine",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-soname,libkdtree.so"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+
+if __name__ == "__main__":
+    build_all(force=True, verbose=True)

@@ -1,0 +1,818 @@
+// engine.hip -- host side of libpct_engine.so: the C ABI of include/pct_engine.h over the
+// gfx950 kernels in kernels.hpp.  One process drives one GPU (pct_init selects it); all work
+// is queued on one library-owned HIP stream unless a caller passes its own (the *_dev entry
+// points), so copies and kernels of a batch stay ordered without host synchronisation.
+//
+// Data layout in HBM per cloud:
+//   x[cap4], y[cap4], z[cap4]   fp32 SoA, insertion order (cap4 = capacity rounded up to 4)
+//   sorted[n]                   float4 {x, y, z, bitcast(original index)} in cell order   (grid only)
+//   cell_start[ncells + 1]      u32 exclusive prefix of per-cell counts                   (grid only)
+//   query workspaces sized by pct_cloud_reserve_queries
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pct_engine.h"
+#include "kernels.hpp"
+
+using namespace pct;
+
+namespace {
+
+thread_local char g_err[512] = "";
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return fail(PCT_ERR_HIP, "%s -> %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define PCTCHK(call)                    \
+    do {                                \
+        int s_ = (call);                \
+        if (s_ != PCT_OK) return s_;    \
+    } while (0)
+
+constexpr int kMaxParts = 2048;       // streaming kernel: at most 8 blocks of 256 per CU
+constexpr int kBezierCapMax = 4096;
+
+template <typename T>
+int dev_alloc(T **p, size_t count)
+{
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, std::max<size_t>(count, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(PCT_ERR_ALLOC, "hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+    *p = static_cast<T *>(v);
+    return PCT_OK;
+}
+
+template <typename T>
+void dev_free(T *&p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+struct pct_cloud {
+    int64_t cap = 0, cap4 = 0, count = 0, ring_next = 0;
+    int64_t index_base = 0;
+    float *x = nullptr, *y = nullptr, *z = nullptr;
+    unsigned char *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // grid
+    bool has_grid = false;
+    GridDesc G{};
+    uint32_t *cell_start = nullptr;
+    size_t cells_cap = 0;
+    float4 *sorted = nullptr;
+    size_t sorted_cap = 0;
+    // query workspaces
+    int64_t qcap = 0;
+    float *d_q = nullptr, *d_r = nullptr;
+    double *d_q64 = nullptr, *d_r2 = nullptr, *d_d2 = nullptr, *d_radius = nullptr, *d_pts64 = nullptr;
+    uint32_t *d_idx = nullptr, *d_count = nullptr;
+    unsigned char *d_skip = nullptr;
+    double *d_part_d2 = nullptr;
+    uint32_t *d_part_idx = nullptr;
+    // bezier
+    double *d_coef = nullptr, *d_segtime = nullptr;
+    int *d_orders = nullptr, *d_nsamples = nullptr;
+    long long *d_first_hit = nullptr;
+    size_t coef_cap = 0, seg_cap = 0;
+    // measurement
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    WorkCounters *d_work = nullptr;
+    bool count_work = false;
+    bool host_work = false;        // last batch's work is known on the host (streaming kernel)
+    uint64_t host_points = 0;
+    bool capturing = false;
+};
+
+struct pct_plan {
+    pct_cloud *c = nullptr;
+    int64_t Q = 0;
+    float *h_q = nullptr;
+    uint32_t *h_idx = nullptr;
+    double *h_d2 = nullptr;
+    float *d_q = nullptr;
+    uint32_t *d_idx = nullptr;
+    double *d_d2 = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+int require_init()
+{
+    if (g_device < 0) return pct_init(0);
+    return PCT_OK;
+}
+
+int ensure_stage(pct_cloud *c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return PCT_OK;
+    dev_free(c->d_stage);
+    c->stage_bytes = 0;
+    PCTCHK(dev_alloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return PCT_OK;
+}
+
+void drop_grid(pct_cloud *c) { c->has_grid = false; }
+
+// host AoS -> device SoA slots [dst0, dst0+n)
+int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64_t dst0)
+{
+    if (n == 0) return PCT_OK;
+    PCTCHK(ensure_stage(c, (size_t)n * stride + 64));
+    HIPCHK(hipMemcpyAsync(c->d_stage, pts, (size_t)n * stride, hipMemcpyHostToDevice, g_stream));
+    if (stride == 12 && (dst0 & 3) == 0 && n >= 4) {
+        const uint32_t ng = (uint32_t)(n >> 2);
+        deinterleave12_kernel<<<ceil_div(ng, 256), 256, 0, g_stream>>>(reinterpret_cast<const float4 *>(c->d_stage), ng,
+                                                                        reinterpret_cast<float4 *>(c->x + dst0),
+                                                                        reinterpret_cast<float4 *>(c->y + dst0),
+                                                                        reinterpret_cast<float4 *>(c->z + dst0));
+        const int64_t done = (int64_t)ng * 4;
+        if (done < n)
+            deinterleave_kernel<<<1, 256, 0, g_stream>>>(c->d_stage + done * 12, 12, (uint32_t)(n - done), c->x, c->y, c->z,
+                                                         (uint32_t)(dst0 + done));
+    } else {
+        deinterleave_kernel<<<ceil_div(n, 256), 256, 0, g_stream>>>(c->d_stage, (uint32_t)stride, (uint32_t)n, c->x, c->y, c->z,
+                                                                    (uint32_t)dst0);
+    }
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int stream_blocks(int64_t n)
+{
+    const int64_t groups = std::max<int64_t>(n >> 2, 1);
+    return (int)std::min<int64_t>(kMaxParts, (groups + 255) / 256);
+}
+
+template <int QT>
+void launch_nn_stream(pct_cloud *c, int blocks, int q0, int qcount, hipStream_t s)
+{
+    nn_stream_kernel<QT><<<blocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_q64, q0, qcount, c->d_part_d2,
+                                                 c->d_part_idx, blocks);
+}
+
+template <int QT>
+void launch_count_stream(pct_cloud *c, int blocks, int q0, int qcount, uint32_t *d_count, hipStream_t s)
+{
+    count_stream_kernel<QT><<<blocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_q64, c->d_r2, q0, qcount, d_count);
+}
+
+int pick_tile(int64_t remaining)
+{
+    if (remaining >= 8) return 8;
+    if (remaining > 2) return 4;
+    if (remaining == 2) return 2;
+    return 1;
+}
+
+void begin_timing(pct_cloud *c, hipStream_t s)
+{
+    c->ev_valid = false;
+    if (c->capturing) return;
+    if (hipEventRecord(c->ev0, s) == hipSuccess) c->ev_valid = true;
+}
+
+void end_timing(pct_cloud *c, hipStream_t s)
+{
+    if (c->capturing || !c->ev_valid) return;
+    if (hipEventRecord(c->ev1, s) != hipSuccess) c->ev_valid = false;
+}
+
+int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+{
+    if (Q == 0) return PCT_OK;
+    if (Q > c->qcap) return fail(PCT_ERR_INVALID, "batch of %lld exceeds reserved %lld (call pct_cloud_reserve_queries)", (long long)Q, (long long)c->qcap);
+    if (c->count == 0) {
+        fill_empty_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(d_idx, d_d2, (uint32_t)Q);
+        HIPCHK(hipGetLastError());
+        return PCT_OK;
+    }
+    if (algo == PCT_ALGO_AUTO) algo = c->has_grid ? PCT_ALGO_GRID : PCT_ALGO_STREAM;
+    if (algo == PCT_ALGO_GRID) {
+        if (!c->has_grid) return fail(PCT_ERR_INVALID, "PCT_ALGO_GRID without a grid (call pct_cloud_build_grid)");
+        c->host_work = false;
+        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
+        begin_timing(c, s);
+        if (c->count_work)
+            nn_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
+                                                                   (uint32_t)c->index_base, d_idx, d_d2, c->d_work);
+        else
+            nn_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
+                                                                    (uint32_t)c->index_base, d_idx, d_d2, c->d_work);
+        end_timing(c, s);
+        HIPCHK(hipGetLastError());
+        return PCT_OK;
+    }
+    if (algo != PCT_ALGO_STREAM) return fail(PCT_ERR_INVALID, "unknown algo %d", algo);
+    widen_queries_kernel<<<ceil_div(3 * Q, 256), 256, 0, s>>>(d_q, (uint32_t)(3 * Q), c->d_q64);
+    const int blocks = stream_blocks(c->count);
+    begin_timing(c, s);
+    for (int64_t q0 = 0; q0 < Q;) {
+        const int qt = pick_tile(Q - q0);
+        const int qcount = (int)std::min<int64_t>(qt, Q - q0);
+        switch (qt) {
+        case 8: launch_nn_stream<8>(c, blocks, (int)q0, qcount, s); break;
+        case 4: launch_nn_stream<4>(c, blocks, (int)q0, qcount, s); break;
+        case 2: launch_nn_stream<2>(c, blocks, (int)q0, qcount, s); break;
+        default: launch_nn_stream<1>(c, blocks, (int)q0, qcount, s); break;
+        }
+        q0 += qcount;
+    }
+    nn_reduce_partials_kernel<<<(int)Q, 64, 0, s>>>(c->d_part_d2, c->d_part_idx, blocks, (uint32_t)c->index_base, d_idx, d_d2);
+    end_timing(c, s);
+    HIPCHK(hipGetLastError());
+    c->host_work = true;                    // the streaming kernel examines every point for every query
+    c->host_points = (uint64_t)Q * (uint64_t)c->count;
+    return PCT_OK;
+}
+
+int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, hipStream_t s)
+{
+    if (Q == 0) return PCT_OK;
+    if (Q > c->qcap) return fail(PCT_ERR_INVALID, "batch of %lld exceeds reserved %lld", (long long)Q, (long long)c->qcap);
+    HIPCHK(hipMemsetAsync(d_count, 0, sizeof(uint32_t) * Q, s));
+    if (c->count == 0) return PCT_OK;
+    if (algo == PCT_ALGO_AUTO) algo = c->has_grid ? PCT_ALGO_GRID : PCT_ALGO_STREAM;
+    if (algo == PCT_ALGO_GRID) {
+        if (!c->has_grid) return fail(PCT_ERR_INVALID, "PCT_ALGO_GRID without a grid");
+        c->host_work = false;
+        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
+        begin_timing(c, s);
+        if (c->count_work)
+            count_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, d_count, c->d_work);
+        else
+            count_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, d_count, c->d_work);
+        end_timing(c, s);
+        HIPCHK(hipGetLastError());
+        return PCT_OK;
+    }
+    if (algo != PCT_ALGO_STREAM) return fail(PCT_ERR_INVALID, "unknown algo %d", algo);
+    widen_queries_kernel<<<ceil_div(3 * Q, 256), 256, 0, s>>>(d_q, (uint32_t)(3 * Q), c->d_q64);
+    square_radii_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(d_r, (uint32_t)Q, c->d_r2);
+    const int blocks = stream_blocks(c->count);
+    begin_timing(c, s);
+    for (int64_t q0 = 0; q0 < Q;) {
+        const int qt = pick_tile(Q - q0);
+        const int qcount = (int)std::min<int64_t>(qt, Q - q0);
+        switch (qt) {
+        case 8: launch_count_stream<8>(c, blocks, (int)q0, qcount, d_count, s); break;
+        case 4: launch_count_stream<4>(c, blocks, (int)q0, qcount, d_count, s); break;
+        case 2: launch_count_stream<2>(c, blocks, (int)q0, qcount, d_count, s); break;
+        default: launch_count_stream<1>(c, blocks, (int)q0, qcount, d_count, s); break;
+        }
+        q0 += qcount;
+    }
+    end_timing(c, s);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+InflateParams to_dev(const pct_inflate_params *p)
+{
+    return InflateParams{ p->start[0], p->start[1], p->start[2], p->sample_range, p->search_margin, p->max_radius };
+}
+
+// pts64 (device, Q x 3) -> radius/idx/d2 in the cloud's workspaces
+int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_t s)
+{
+    const InflateParams P = to_dev(p);
+    inflate_prologue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, c->d_pts64, (uint32_t)Q, c->d_q, c->d_skip);
+    if (c->count > 0) PCTCHK(nn_dev(c, PCT_ALGO_AUTO, c->d_q, Q, c->d_idx, c->d_d2, s));
+    inflate_epilogue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, c->d_radius);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+}  // namespace
+
+// ======================================================================================
+//  C ABI
+// ======================================================================================
+extern "C" {
+
+const char *pct_last_error(void) { return g_err; }
+
+int pct_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pct_init(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(PCT_ERR_NO_DEVICE, "no HIP device (%s); this library has no host fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(PCT_ERR_INVALID, "device %d out of range (0..%d)", device, n - 1);
+    HIPCHK(hipSetDevice(device));
+    if (g_stream && g_device != device) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (!g_stream) HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    return PCT_OK;
+}
+
+int pct_sync(void)
+{
+    PCTCHK(require_init());
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
+
+int pct_cloud_create(int64_t capacity, pct_cloud **out)
+{
+    if (!out || capacity < 0 || capacity > 0xFFFFFFF0ll) return fail(PCT_ERR_INVALID, "bad capacity");
+    PCTCHK(require_init());
+    pct_cloud *c = new (std::nothrow) pct_cloud();
+    if (!c) return fail(PCT_ERR_ALLOC, "host allocation failed");
+    c->cap = capacity;
+    c->cap4 = (capacity + 3) & ~3ll;
+    int s;
+    if ((s = dev_alloc(&c->x, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->y, (size_t)c->cap4 + 4)) ||
+        (s = dev_alloc(&c->z, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->d_work, 1))) {
+        pct_cloud_destroy(c);
+        return s;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        pct_cloud_destroy(c);
+        return fail(PCT_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = c;
+    return PCT_OK;
+}
+
+int pct_cloud_destroy(pct_cloud *c)
+{
+    if (!c) return PCT_OK;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
+    dev_free(c->cell_start); dev_free(c->sorted);
+    dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
+    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx);
+    dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
+    dev_free(c->d_work);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+    return PCT_OK;
+}
+
+int64_t pct_cloud_size(const pct_cloud *c) { return c ? c->count : 0; }
+int64_t pct_cloud_capacity(const pct_cloud *c) { return c ? c->cap : 0; }
+
+int pct_cloud_set_index_base(pct_cloud *c, int64_t base)
+{
+    if (!c || base < 0 || base + c->cap > 0xFFFFFFF0ll) return fail(PCT_ERR_INVALID, "bad index base");
+    c->index_base = base;
+    return PCT_OK;
+}
+
+int pct_cloud_upload_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes)
+{
+    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes & 3)) return fail(PCT_ERR_INVALID, "bad upload arguments");
+    if (n > c->cap) return fail(PCT_ERR_CAPACITY, "%lld points > capacity %lld", (long long)n, (long long)c->cap);
+    drop_grid(c);
+    PCTCHK(upload_range(c, pts, n, stride_bytes, 0));
+    HIPCHK(hipStreamSynchronize(g_stream));    // the host buffer is the caller's again
+    c->count = n;
+    c->ring_next = n % std::max<int64_t>(c->cap, 1);
+    return PCT_OK;
+}
+
+int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n)
+{
+    if (!c || n < 0 || (n > 0 && (!d_x || !d_y || !d_z))) return fail(PCT_ERR_INVALID, "bad upload arguments");
+    if (n > c->cap) return fail(PCT_ERR_CAPACITY, "%lld points > capacity %lld", (long long)n, (long long)c->cap);
+    drop_grid(c);
+    if (n) {
+        HIPCHK(hipMemcpyAsync(c->x, d_x, sizeof(float) * n, hipMemcpyDeviceToDevice, g_stream));
+        HIPCHK(hipMemcpyAsync(c->y, d_y, sizeof(float) * n, hipMemcpyDeviceToDevice, g_stream));
+        HIPCHK(hipMemcpyAsync(c->z, d_z, sizeof(float) * n, hipMemcpyDeviceToDevice, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
+    c->count = n;
+    c->ring_next = n % std::max<int64_t>(c->cap, 1);
+    return PCT_OK;
+}
+
+int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes)
+{
+    if (!c || n < 0 || (n > 0 && !pts) || stride_bytes < 12 || (stride_bytes & 3)) return fail(PCT_ERR_INVALID, "bad append arguments");
+    if (n > c->cap) return fail(PCT_ERR_CAPACITY, "appending %lld points to a ring of %lld", (long long)n, (long long)c->cap);
+    if (n == 0) return PCT_OK;
+    drop_grid(c);
+    const int64_t first = std::min(n, c->cap - c->ring_next);
+    PCTCHK(upload_range(c, pts, first, stride_bytes, c->ring_next));
+    HIPCHK(hipStreamSynchronize(g_stream));   // the staging buffer is reused by the wrapped part
+    if (first < n) {
+        PCTCHK(upload_range(c, static_cast<const unsigned char *>(pts) + first * stride_bytes, n - first, stride_bytes, 0));
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
+    c->ring_next = (c->ring_next + n) % c->cap;
+    c->count = std::min(c->cap, c->count + n);
+    return PCT_OK;
+}
+
+int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
+{
+    if (!c || Q < 0) return fail(PCT_ERR_INVALID, "bad reserve");
+    if (Q <= c->qcap) return PCT_OK;
+    if (c->capturing) return fail(PCT_ERR_INVALID, "cannot grow workspaces during graph capture");
+    HIPCHK(hipStreamSynchronize(g_stream));
+    const int64_t q = std::max<int64_t>(Q, 256);
+    dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
+    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx);
+    c->qcap = 0;
+    PCTCHK(dev_alloc(&c->d_q, 3 * q));
+    PCTCHK(dev_alloc(&c->d_r, q));
+    PCTCHK(dev_alloc(&c->d_q64, 3 * q));
+    PCTCHK(dev_alloc(&c->d_r2, q));
+    PCTCHK(dev_alloc(&c->d_d2, q));
+    PCTCHK(dev_alloc(&c->d_radius, q));
+    PCTCHK(dev_alloc(&c->d_pts64, 3 * q));
+    PCTCHK(dev_alloc(&c->d_idx, q));
+    PCTCHK(dev_alloc(&c->d_count, q));
+    PCTCHK(dev_alloc(&c->d_skip, q));
+    PCTCHK(dev_alloc(&c->d_part_d2, (size_t)q * kMaxParts));
+    PCTCHK(dev_alloc(&c->d_part_idx, (size_t)q * kMaxParts));
+    c->qcap = q;
+    return PCT_OK;
+}
+
+// ---- grid ------------------------------------------------------------------------------
+int pct_cloud_drop_grid(pct_cloud *c)
+{
+    if (!c) return fail(PCT_ERR_INVALID, "null cloud");
+    drop_grid(c);
+    return PCT_OK;
+}
+
+int pct_cloud_has_grid(const pct_cloud *c) { return c && c->has_grid ? 1 : 0; }
+
+int pct_cloud_grid_info(const pct_cloud *c, int32_t dims[3], float *cell_size, float origin[3], int64_t *ncells)
+{
+    if (!c || !c->has_grid) return fail(PCT_ERR_INVALID, "no grid");
+    if (dims) { dims[0] = c->G.gx; dims[1] = c->G.gy; dims[2] = c->G.gz; }
+    if (cell_size) *cell_size = (float)c->G.hd;
+    if (origin) { origin[0] = c->G.ox; origin[1] = c->G.oy; origin[2] = c->G.oz; }
+    if (ncells) *ncells = c->G.ncells;
+    return PCT_OK;
+}
+
+int pct_cloud_build_grid(pct_cloud *c, float cell_size)
+{
+    if (!c) return fail(PCT_ERR_INVALID, "null cloud");
+    drop_grid(c);
+    const int64_t n = c->count;
+    if (n == 0) return fail(PCT_ERR_EMPTY, "cannot index an empty cloud");
+    hipStream_t s = g_stream;
+
+    // 1. bounding box
+    const int bblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    float *d_part = nullptr;
+    PCTCHK(dev_alloc(&d_part, (size_t)bblocks * 6));
+    bbox_partial_kernel<<<bblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_part);
+    std::vector<float> part((size_t)bblocks * 6);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(d_part);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "bbox reduction failed: %s", hipGetErrorString(e));
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int b = 0; b < bblocks; b++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], part[(size_t)b * 6 + k]);
+            hi[k] = std::max(hi[k], part[(size_t)b * 6 + 3 + k]);
+        }
+    for (int k = 0; k < 3; k++)
+        if (!std::isfinite(lo[k]) || !std::isfinite(hi[k])) return fail(PCT_ERR_INVALID, "cloud holds non-finite coordinates");
+
+    // 2. cell size: about 2 points per cell over the occupied bounding box, dims capped at 1024/axis
+    double ext[3];
+    for (int k = 0; k < 3; k++) ext[k] = std::max((double)hi[k] - (double)lo[k], 0.0);
+    double h = cell_size;
+    if (!(h > 0)) {
+        const double diag = std::max({ ext[0], ext[1], ext[2], 1e-6 });
+        double vol = 1.0;
+        for (int k = 0; k < 3; k++) vol *= std::max(ext[k], diag * 1e-3);
+        h = std::cbrt(vol * 2.0 / (double)n);
+    }
+    const double max_ext = std::max({ ext[0], ext[1], ext[2] });
+    h = std::max(h, max_ext / 1023.0);
+    if (!(h > 0)) h = 1.0;   // all points identical
+    const float hf = (float)h;
+    GridDesc G{};
+    G.ox = lo[0]; G.oy = lo[1]; G.oz = lo[2];
+    G.inv_h = 1.0f / hf;
+    G.oxd = lo[0]; G.oyd = lo[1]; G.ozd = lo[2];
+    G.hd = (double)hf;
+    G.gx = std::max(1, std::min(1024, (int)std::floor(ext[0] / G.hd) + 1));
+    G.gy = std::max(1, std::min(1024, (int)std::floor(ext[1] / G.hd) + 1));
+    G.gz = std::max(1, std::min(1024, (int)std::floor(ext[2] / G.hd) + 1));
+    const uint64_t ncells = (uint64_t)G.gx * G.gy * G.gz;
+    if (ncells > 0x7FFFFFF0ull) return fail(PCT_ERR_INVALID, "grid of %llu cells is too large", (unsigned long long)ncells);
+    G.ncells = (uint32_t)ncells;
+
+    // 3. counting sort
+    if (ncells + 1 > c->cells_cap) {
+        dev_free(c->cell_start);
+        c->cells_cap = 0;
+        PCTCHK(dev_alloc(&c->cell_start, ncells + 1));
+        c->cells_cap = ncells + 1;
+    }
+    if ((size_t)n > c->sorted_cap) {
+        dev_free(c->sorted);
+        c->sorted_cap = 0;
+        PCTCHK(dev_alloc(&c->sorted, (size_t)n));
+        c->sorted_cap = (size_t)n;
+    }
+    uint32_t *d_cnt = nullptr, *d_pcell = nullptr, *d_tiles = nullptr;
+    const uint32_t ntiles = (uint32_t)((ncells + kScanTile - 1) / kScanTile);
+    int st = dev_alloc(&d_cnt, ncells);
+    if (!st) st = dev_alloc(&d_pcell, (size_t)n);
+    if (!st) st = dev_alloc(&d_tiles, ntiles);
+    if (st) { dev_free(d_cnt); dev_free(d_pcell); dev_free(d_tiles); return st; }
+    e = hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * ncells, s);
+    const int pblocks = (int)std::min<int64_t>(4096, (n + 255) / 256);
+    if (e == hipSuccess) {
+        cell_histogram_kernel<<<pblocks, 256, 0, s>>>(G, c->x, c->y, c->z, (uint32_t)n, d_cnt, d_pcell);
+        scan_tiles_kernel<<<ntiles, 256, 0, s>>>(d_cnt, (uint32_t)ncells, c->cell_start, d_tiles);
+        scan_tile_sums_kernel<<<1, 256, 0, s>>>(d_tiles, ntiles);
+        scan_add_kernel<<<ceil_div((int64_t)ncells, 256), 256, 0, s>>>(c->cell_start, (uint32_t)ncells, d_tiles, (uint32_t)n);
+        e = hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * ncells, s);
+    }
+    if (e == hipSuccess) {
+        cell_scatter_kernel<<<pblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_pcell, c->cell_start, d_cnt, c->sorted);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(d_cnt); dev_free(d_pcell); dev_free(d_tiles);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
+    c->G = G;
+    c->has_grid = true;
+    return PCT_OK;
+}
+
+// ---- device-buffer entry points --------------------------------------------------------
+int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream)
+{
+    if (!c || Q < 0 || (Q > 0 && (!d_q || !d_idx || !d_d2))) return fail(PCT_ERR_INVALID, "bad nn_batch_dev arguments");
+    return nn_dev(c, algo, d_q, Q, d_idx, d_d2, stream ? (hipStream_t)stream : g_stream);
+}
+
+int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream)
+{
+    if (!c || Q < 0 || (Q > 0 && (!d_q || !d_r || !d_count))) return fail(PCT_ERR_INVALID, "bad radius_count_batch_dev arguments");
+    return count_dev(c, algo, d_q, d_r, Q, d_count, stream ? (hipStream_t)stream : g_stream);
+}
+
+// ---- host-buffer entry points ----------------------------------------------------------
+int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_t *idx, double *d2)
+{
+    if (!c || Q < 0 || (Q > 0 && (!q || !idx || !d2))) return fail(PCT_ERR_INVALID, "bad nn_batch arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(pct_cloud_reserve_queries(c, Q));
+    HIPCHK(hipMemcpyAsync(c->d_q, q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+    PCTCHK(nn_dev(c, algo, c->d_q, Q, c->d_idx, c->d_d2, g_stream));
+    HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(d2, c->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (c->count == 0) return fail(PCT_ERR_EMPTY, "nearest-neighbour query against an empty cloud");
+    return PCT_OK;
+}
+
+int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double *d2)
+{
+    return pct_nn_batch_algo(c, PCT_ALGO_AUTO, q, Q, idx, d2);
+}
+
+int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const float *r, int64_t Q, uint32_t *count)
+{
+    if (!c || Q < 0 || (Q > 0 && (!q || !r || !count))) return fail(PCT_ERR_INVALID, "bad radius_count arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(pct_cloud_reserve_queries(c, Q));
+    HIPCHK(hipMemcpyAsync(c->d_q, q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+    HIPCHK(hipMemcpyAsync(c->d_r, r, sizeof(float) * Q, hipMemcpyHostToDevice, g_stream));
+    PCTCHK(count_dev(c, algo, c->d_q, c->d_r, Q, c->d_count, g_stream));
+    HIPCHK(hipMemcpyAsync(count, c->d_count, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
+
+int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t Q, uint32_t *count)
+{
+    return pct_radius_count_batch_algo(c, PCT_ALGO_AUTO, q, r, Q, count);
+}
+
+int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out)
+{
+    if (!c || !q || cap < 0 || (cap > 0 && !idx_out) || !n_out) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
+    *n_out = 0;
+    if (c->count == 0) return PCT_OK;
+    uint32_t *d_out = nullptr, *d_cursor = nullptr;
+    PCTCHK(dev_alloc(&d_out, (size_t)std::max<int64_t>(cap, 1)));
+    int st = dev_alloc(&d_cursor, 1);
+    if (st) { dev_free(d_out); return st; }
+    hipError_t e = hipMemsetAsync(d_cursor, 0, sizeof(uint32_t), g_stream);
+    const int blocks = (int)std::min<int64_t>(4096, (c->count + 255) / 256);
+    const double rr = (double)r * (double)r;
+    radius_collect_kernel<<<blocks, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, (double)q[0], (double)q[1], (double)q[2], rr,
+                                                         (uint32_t)c->index_base, d_out, (uint32_t)cap, d_cursor);
+    uint32_t total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, sizeof total, hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    const int64_t got = std::min<int64_t>(total, cap);
+    if (e == hipSuccess && got > 0) e = hipMemcpy(idx_out, d_out, sizeof(uint32_t) * got, hipMemcpyDeviceToHost);
+    dev_free(d_out); dev_free(d_cursor);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "radius_indices failed: %s", hipGetErrorString(e));
+    std::sort(idx_out, idx_out + got);   // ascending index order (the kernel appends in arrival order)
+    *n_out = total;
+    return PCT_OK;
+}
+
+int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *pts, int64_t Q, double *radius, uint32_t *idx, double *d2)
+{
+    if (!c || !p || Q < 0 || (Q > 0 && (!pts || !radius))) return fail(PCT_ERR_INVALID, "bad inflate arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(pct_cloud_reserve_queries(c, Q));
+    HIPCHK(hipMemcpyAsync(c->d_pts64, pts, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+    PCTCHK(inflate_dev(c, p, Q, g_stream));
+    HIPCHK(hipMemcpyAsync(radius, c->d_radius, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+    if (idx) HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
+    if (d2) HIPCHK(hipMemcpyAsync(d2, c->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
+
+int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflate_params *p, double t_start, double stop_time, double dt,
+                     int64_t *first_hit, int64_t *nsamples, int64_t cap, double *pos, double *radius, double *d2, uint32_t *idx)
+{
+    if (!c || !traj || !p || !first_hit || !nsamples || !traj->polycoef || !traj->seg_time || !traj->orders || traj->nseg <= 0 ||
+        !(dt > 0) || cap <= 0)
+        return fail(PCT_ERR_INVALID, "bad bezier_check arguments");
+    if (cap > kBezierCapMax) cap = kBezierCapMax;
+    for (int i = 0; i < traj->nseg; i++)
+        if (traj->orders[i] < 0 || traj->orders[i] > kMaxBezierOrder || 3 * (traj->orders[i] + 1) > traj->row_stride)
+            return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
+    PCTCHK(pct_cloud_reserve_queries(c, cap));
+    const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
+    if (ncoef > c->coef_cap) { dev_free(c->d_coef); c->coef_cap = 0; PCTCHK(dev_alloc(&c->d_coef, ncoef)); c->coef_cap = ncoef; }
+    if ((size_t)traj->nseg > c->seg_cap) {
+        dev_free(c->d_segtime); dev_free(c->d_orders); c->seg_cap = 0;
+        PCTCHK(dev_alloc(&c->d_segtime, traj->nseg));
+        PCTCHK(dev_alloc(&c->d_orders, traj->nseg));
+        c->seg_cap = traj->nseg;
+    }
+    if (!c->d_nsamples) PCTCHK(dev_alloc(&c->d_nsamples, 1));
+    if (!c->d_first_hit) PCTCHK(dev_alloc(&c->d_first_hit, 1));
+    hipStream_t s = g_stream;
+    HIPCHK(hipMemcpyAsync(c->d_coef, traj->polycoef, sizeof(double) * ncoef, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_segtime, traj->seg_time, sizeof(double) * traj->nseg, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_orders, traj->orders, sizeof(int) * traj->nseg, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(c->d_pts64, 0, sizeof(double) * 3 * cap, s));
+    BezierDesc B{ c->d_coef, c->d_segtime, c->d_orders, (int)traj->row_stride, traj->nseg, t_start, stop_time, dt, (int)cap };
+    const size_t smem = (size_t)cap * (sizeof(double) + sizeof(int));
+    bezier_samples_kernel<<<1, 256, smem, s>>>(B, c->d_pts64, c->d_nsamples);
+    PCTCHK(inflate_dev(c, p, cap, s));
+    first_hit_kernel<<<1, 256, 0, s>>>(c->d_radius, c->d_nsamples, (int)cap, c->d_first_hit);
+    HIPCHK(hipGetLastError());
+    int ns = 0;
+    long long fh = -1;
+    HIPCHK(hipMemcpyAsync(&ns, c->d_nsamples, sizeof ns, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&fh, c->d_first_hit, sizeof fh, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int64_t m = std::min<int64_t>(ns, cap);
+    if (pos && m) HIPCHK(hipMemcpy(pos, c->d_pts64, sizeof(double) * 3 * m, hipMemcpyDeviceToHost));
+    if (radius && m) HIPCHK(hipMemcpy(radius, c->d_radius, sizeof(double) * m, hipMemcpyDeviceToHost));
+    if (d2 && m) HIPCHK(hipMemcpy(d2, c->d_d2, sizeof(double) * m, hipMemcpyDeviceToHost));
+    if (idx && m) HIPCHK(hipMemcpy(idx, c->d_idx, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
+    *nsamples = ns;
+    *first_hit = fh;
+    return PCT_OK;
+}
+
+// ---- hipGraph plan -----------------------------------------------------------------------
+int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out)
+{
+    if (!c || !out || Q <= 0) return fail(PCT_ERR_INVALID, "bad plan arguments");
+    PCTCHK(pct_cloud_reserve_queries(c, Q));
+    pct_plan *p = new (std::nothrow) pct_plan();
+    if (!p) return fail(PCT_ERR_ALLOC, "host allocation failed");
+    p->c = c;
+    p->Q = Q;
+    hipError_t e = hipHostMalloc((void **)&p->h_q, sizeof(float) * 3 * Q, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_idx, sizeof(uint32_t) * Q, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_d2, sizeof(double) * Q, hipHostMallocDefault);
+    int st = PCT_OK;
+    if (e != hipSuccess) st = fail(PCT_ERR_ALLOC, "hipHostMalloc: %s", hipGetErrorString(e));
+    if (!st) st = dev_alloc(&p->d_q, 3 * Q);
+    if (!st) st = dev_alloc(&p->d_idx, Q);
+    if (!st) st = dev_alloc(&p->d_d2, Q);
+    if (st) { pct_plan_destroy(p); return st; }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+    c->capturing = true;
+    (void)hipMemcpyAsync(p->d_q, p->h_q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream);
+    st = nn_dev(c, algo, p->d_q, Q, p->d_idx, p->d_d2, g_stream);
+    (void)hipMemcpyAsync(p->h_idx, p->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream);
+    (void)hipMemcpyAsync(p->h_d2, p->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream);
+    c->capturing = false;
+    e = hipStreamEndCapture(g_stream, &p->graph);
+    if (st != PCT_OK) { pct_plan_destroy(p); return st; }
+    if (e != hipSuccess || !p->graph) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    *out = p;
+    return PCT_OK;
+}
+
+int pct_plan_run(pct_plan *p, const float *q, uint32_t *idx, double *d2)
+{
+    if (!p || !q || !idx || !d2) return fail(PCT_ERR_INVALID, "bad plan_run arguments");
+    memcpy(p->h_q, q, sizeof(float) * 3 * p->Q);
+    HIPCHK(hipGraphLaunch(p->exec, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    memcpy(idx, p->h_idx, sizeof(uint32_t) * p->Q);
+    memcpy(d2, p->h_d2, sizeof(double) * p->Q);
+    return PCT_OK;
+}
+
+int pct_plan_destroy(pct_plan *p)
+{
+    if (!p) return PCT_OK;
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->h_q) (void)hipHostFree(p->h_q);
+    if (p->h_idx) (void)hipHostFree(p->h_idx);
+    if (p->h_d2) (void)hipHostFree(p->h_d2);
+    dev_free(p->d_q); dev_free(p->d_idx); dev_free(p->d_d2);
+    delete p;
+    return PCT_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------
+int pct_last_kernel_ms(pct_cloud *c, float *ms)
+{
+    if (!c || !ms) return fail(PCT_ERR_INVALID, "bad arguments");
+    if (!c->ev_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
+    HIPCHK(hipEventSynchronize(c->ev1));
+    HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PCT_OK;
+}
+
+int pct_set_work_counters(pct_cloud *c, int enabled)
+{
+    if (!c) return fail(PCT_ERR_INVALID, "null cloud");
+    c->count_work = enabled != 0;
+    return PCT_OK;
+}
+
+int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned)
+{
+    if (!c) return fail(PCT_ERR_INVALID, "null cloud");
+    WorkCounters w{};
+    if (c->host_work) {
+        w.points = c->host_points;
+    } else {
+        HIPCHK(hipStreamSynchronize(g_stream));
+        HIPCHK(hipMemcpy(&w, c->d_work, sizeof w, hipMemcpyDeviceToHost));
+    }
+    if (points_scanned) *points_scanned = w.points;
+    if (cells_scanned) *cells_scanned = w.cells;
+    return PCT_OK;
+}
+
+}  // extern "C"

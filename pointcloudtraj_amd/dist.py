@@ -1,0 +1,120 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm, "gloo" for the CPU tests).  SURVEY.md section 8(e): the cloud is split into contiguous
+index ranges, every rank answers the whole (replicated) query batch against its shard, and one
+exchange step merges the per-shard winners:
+
+    d2*  = all_reduce(min) over ranks of the per-shard squared distances      (fp64, exact)
+    idx* = all_reduce(min) of  (idx_r  if d2_r == d2*  else  INT64_MAX)        -> lowest global index
+    count = all_reduce(sum) of per-shard radius counts
+
+Global index = shard base + local index, and shards are contiguous ascending ranges, so "lowest
+index among fp64-equal minima" is preserved across the merge.  Messages are Q*8 bytes: the
+collective is latency-bound, so it is issued once per batch on the stream the kernels ran on.
+
+torch is plumbing here (device memory, streams, process groups); all distance arithmetic happens
+in the HIP kernels of libpct_engine.so.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_I64_MAX = torch.iinfo(torch.int64).max
+
+
+def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
+    """[begin, end) of rank's contiguous slice: rank r owns [r*n/world, (r+1)*n/world)."""
+    return (rank * n_total) // world, ((rank + 1) * n_total) // world
+
+
+def merge_nearest(d2: torch.Tensor, idx: torch.Tensor, group=None) -> tuple[torch.Tensor, torch.Tensor]:
+    """Exchange step for 1-NN.  d2: fp64 [Q] per-shard minima (+inf for an empty shard);
+    idx: int64 [Q] GLOBAL indices (anything where d2 is +inf).  Returns the global (d2, idx)."""
+    best = d2.clone()
+    dist.all_reduce(best, op=dist.ReduceOp.MIN, group=group)
+    cand = torch.where((d2 == best) & torch.isfinite(d2), idx, torch.full_like(idx, _I64_MAX))
+    dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
+    return best, cand
+
+
+def merge_counts(count: torch.Tensor, group=None) -> torch.Tensor:
+    total = count.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return total
+
+
+def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the environment (torch.distributed.run)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class ShardedCloud:
+    """This rank's contiguous shard of a global cloud, resident in this rank's HBM."""
+
+    def __init__(self, n_total: int, rank: int, world: int, device_index: int, group=None):
+        from . import engine as E   # HIP runtime is loaded here; torch is already imported (see engine._preload_hip_runtime)
+        self.E = E
+        self.rank, self.world, self.group = rank, world, group
+        self.n_total = int(n_total)
+        self.begin, self.end = shard_range(self.n_total, rank, world)
+        torch.cuda.set_device(device_index)
+        E.init(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.cloud = E.Cloud(max(self.end - self.begin, 1))
+        self.cloud.set_index_base(self.begin)
+
+    def set_input_local(self, local_points: np.ndarray):
+        """local_points = rows [begin, end) of the global cloud."""
+        assert len(local_points) == self.end - self.begin
+        self.cloud.set_input(local_points)
+
+    def build_grid(self, cell_size: float = 0.0):
+        if len(self.cloud):
+            self.cloud.build_grid(cell_size)
+
+    def reserve(self, Q: int):
+        self.cloud.reserve_queries(Q)
+        self._idx32 = torch.empty(Q, dtype=torch.int32, device=self.device)
+        self._d2 = torch.empty(Q, dtype=torch.float64, device=self.device)
+        self._cnt = torch.empty(Q, dtype=torch.int32, device=self.device)
+
+    def nn_local(self, q: torch.Tensor, algo: int = 0):
+        """Per-shard kernel on torch's current stream.  q: float32 [Q,3] on this device."""
+        Q = q.shape[0]
+        s = torch.cuda.current_stream().cuda_stream
+        self.cloud.nn_device(q.data_ptr(), Q, self._idx32.data_ptr(), self._d2.data_ptr(), s, algo)
+        # u32 -> int64 (NO_INDEX stays recognisable through d2 == +inf)
+        idx = self._idx32[:Q].to(torch.int64) & 0xFFFFFFFF
+        return self._d2[:Q], idx
+
+    def nn(self, q: torch.Tensor, algo: int = 0):
+        d2, idx = self.nn_local(q, algo)
+        if self.world == 1:
+            return d2, idx
+        return merge_nearest(d2, idx, self.group)
+
+    def radius_count(self, q: torch.Tensor, r: torch.Tensor, algo: int = 0):
+        Q = q.shape[0]
+        s = torch.cuda.current_stream().cuda_stream
+        self.cloud.radius_count_device(q.data_ptr(), r.data_ptr(), Q, self._cnt.data_ptr(), s, algo)
+        cnt = self._cnt[:Q].to(torch.int64)
+        return cnt if self.world == 1 else merge_counts(cnt, self.group)
+
+    def close(self):
+        self.cloud.close()

@@ -1,0 +1,293 @@
+"""ctypes binding of libpct_engine.so (include/pct_engine.h) -- the host-side mirror used by the
+tests, bench.py and the torch.distributed sharding layer.  Plumbing only: every number comes
+from the HIP kernels; a missing library or a missing GPU raises, there is no fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NO_INDEX = 0xFFFFFFFF
+ALGO_AUTO, ALGO_STREAM, ALGO_GRID = 0, 1, 2
+
+_lib = None
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"pct_engine status {code}: {msg}")
+        self.code = code
+
+
+class InflateParams(C.Structure):
+    _fields_ = [("start", C.c_double * 3), ("sample_range", C.c_double), ("search_margin", C.c_double),
+                ("max_radius", C.c_double)]
+
+
+class BezierTraj(C.Structure):
+    _fields_ = [("polycoef", C.POINTER(C.c_double)), ("row_stride", C.c_int64), ("seg_time", C.POINTER(C.c_double)),
+                ("orders", C.POINTER(C.c_int32)), ("nseg", C.c_int32)]
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (soname
+    libamdhip64.so.7, the same as /opt/rocm's); two copies in one process each open the KFD device
+    and the second one sees no GPU.  Loading torch's copy FIRST makes libpct_engine.so's
+    DT_NEEDED libamdhip64.so.7 resolve to it by soname, and a later `import torch` finds the same
+    file already mapped.  Without torch installed the system runtime is used as linked."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    """Load (never build implicitly on a GPU box: the .so travels with the snapshot)."""
+    global _lib
+    if _lib is None:
+        _preload_hip_runtime()
+        if not os.path.exists(_build.ENGINE_SO):
+            raise FileNotFoundError(f"{_build.ENGINE_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(the HIP extension is mandatory; there is no CPU fallback)")
+        L = C.CDLL(_build.ENGINE_SO)
+        vp, i64, i32, u32p, f32p, f64p = C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p
+        L.pct_last_error.restype = C.c_char_p
+        L.pct_init.argtypes = [i32]
+        L.pct_cloud_create.argtypes = [i64, C.POINTER(vp)]
+        L.pct_cloud_destroy.argtypes = [vp]
+        L.pct_cloud_size.restype = i64
+        L.pct_cloud_size.argtypes = [vp]
+        L.pct_cloud_capacity.restype = i64
+        L.pct_cloud_capacity.argtypes = [vp]
+        L.pct_cloud_set_index_base.argtypes = [vp, i64]
+        L.pct_cloud_upload_aos.argtypes = [vp, vp, i64, i64]
+        L.pct_cloud_upload_soa_dev.argtypes = [vp, vp, vp, vp, i64]
+        L.pct_cloud_append_aos.argtypes = [vp, vp, i64, i64]
+        L.pct_cloud_build_grid.argtypes = [vp, C.c_float]
+        L.pct_cloud_drop_grid.argtypes = [vp]
+        L.pct_cloud_has_grid.argtypes = [vp]
+        L.pct_cloud_grid_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i64)]
+        L.pct_nn_batch.argtypes = [vp, f32p, i64, u32p, f64p]
+        L.pct_nn_batch_algo.argtypes = [vp, i32, f32p, i64, u32p, f64p]
+        L.pct_radius_count_batch.argtypes = [vp, f32p, f32p, i64, u32p]
+        L.pct_radius_count_batch_algo.argtypes = [vp, i32, f32p, f32p, i64, u32p]
+        L.pct_radius_indices.argtypes = [vp, f32p, C.c_float, u32p, i64, C.POINTER(i64)]
+        L.pct_inflate_batch.argtypes = [vp, C.POINTER(InflateParams), f64p, i64, f64p, u32p, f64p]
+        L.pct_bezier_check.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.c_double, C.c_double,
+                                       C.POINTER(i64), C.POINTER(i64), i64, f64p, f64p, f64p, u32p]
+        L.pct_nn_batch_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
+        L.pct_radius_count_batch_dev.argtypes = [vp, i32, vp, vp, i64, vp, vp]
+        L.pct_cloud_reserve_queries.argtypes = [vp, i64]
+        L.pct_plan_create_nn.argtypes = [vp, i32, i64, C.POINTER(vp)]
+        L.pct_plan_run.argtypes = [vp, f32p, u32p, f64p]
+        L.pct_plan_destroy.argtypes = [vp]
+        L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.pct_set_work_counters.argtypes = [vp, i32]
+        _lib = L
+    return _lib
+
+
+def _chk(code):
+    if code != 0:
+        raise EngineError(code, lib().pct_last_error().decode(errors="replace"))
+
+
+def init(device: int = 0):
+    _chk(lib().pct_init(device))
+
+
+def device_count() -> int:
+    return lib().pct_device_count()
+
+
+def sync():
+    _chk(lib().pct_sync())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def inflate_params(start, sample_range, search_margin, max_radius) -> InflateParams:
+    p = InflateParams()
+    p.start[:] = [float(v) for v in start]
+    p.sample_range, p.search_margin, p.max_radius = float(sample_range), float(search_margin), float(max_radius)
+    return p
+
+
+class Cloud:
+    """An obstacle cloud resident in HBM (pct_cloud).  Mirrors the planner seam:
+    set_input ~ safeRegionRrtStar::setInput (corridor_finder.cpp:93-99), inflate ~ radiusSearch
+    (:113-133), bezier_check ~ checkSafeTrajectory (sim_planning_demo.cpp:729-781)."""
+
+    def __init__(self, capacity: int):
+        self._h = C.c_void_p()
+        _chk(lib().pct_cloud_create(int(capacity), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().pct_cloud_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __len__(self):
+        return lib().pct_cloud_size(self._h)
+
+    @property
+    def capacity(self):
+        return lib().pct_cloud_capacity(self._h)
+
+    def set_index_base(self, base: int):
+        _chk(lib().pct_cloud_set_index_base(self._h, int(base)))
+
+    @staticmethod
+    def _aos(points):
+        a = np.asarray(points)
+        if a.dtype != np.float32 or not a.flags.c_contiguous:
+            a = np.ascontiguousarray(a, np.float32)
+        if a.ndim != 2 or a.shape[1] not in (3, 4):
+            raise ValueError("points must be (n,3) packed xyz or (n,4) pcl::PointXYZ-style records")
+        return a, a.shape[1] * 4
+
+    def set_input(self, points):
+        a, stride = self._aos(points)
+        _chk(lib().pct_cloud_upload_aos(self._h, _ptr(a), len(a), stride))
+
+    def set_input_device(self, x_ptr: int, y_ptr: int, z_ptr: int, n: int):
+        _chk(lib().pct_cloud_upload_soa_dev(self._h, x_ptr, y_ptr, z_ptr, int(n)))
+
+    def append(self, points):
+        a, stride = self._aos(points)
+        _chk(lib().pct_cloud_append_aos(self._h, _ptr(a), len(a), stride))
+
+    def build_grid(self, cell_size: float = 0.0):
+        _chk(lib().pct_cloud_build_grid(self._h, float(cell_size)))
+
+    def drop_grid(self):
+        _chk(lib().pct_cloud_drop_grid(self._h))
+
+    @property
+    def has_grid(self) -> bool:
+        return bool(lib().pct_cloud_has_grid(self._h))
+
+    def grid_info(self):
+        dims = (C.c_int32 * 3)()
+        h = C.c_float()
+        org = (C.c_float * 3)()
+        nc = C.c_int64()
+        _chk(lib().pct_cloud_grid_info(self._h, dims, C.byref(h), org, C.byref(nc)))
+        return dict(dims=tuple(dims), cell_size=h.value, origin=tuple(org), ncells=nc.value)
+
+    def reserve_queries(self, Q: int):
+        _chk(lib().pct_cloud_reserve_queries(self._h, int(Q)))
+
+    def nn(self, queries, algo: int = ALGO_AUTO):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)
+        idx = np.empty(len(q), np.uint32)
+        d2 = np.empty(len(q), np.float64)
+        _chk(lib().pct_nn_batch_algo(self._h, algo, _ptr(q), len(q), _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def radius_count(self, queries, radii, algo: int = ALGO_AUTO):
+        q = np.ascontiguousarray(queries, np.float32).reshape(-1, 3)
+        r = np.ascontiguousarray(np.broadcast_to(np.asarray(radii, np.float32), (len(q),)))
+        cnt = np.empty(len(q), np.uint32)
+        _chk(lib().pct_radius_count_batch_algo(self._h, algo, _ptr(q), _ptr(r), len(q), _ptr(cnt)))
+        return cnt
+
+    def radius_indices(self, center, radius, cap=None):
+        q = np.ascontiguousarray(center, np.float32).reshape(3)
+        cap = int(cap if cap is not None else max(len(self), 1))
+        out = np.empty(cap, np.uint32)
+        n = C.c_int64()
+        _chk(lib().pct_radius_indices(self._h, _ptr(q), float(radius), _ptr(out), cap, C.byref(n)))
+        return out[:min(n.value, cap)].copy(), n.value
+
+    def inflate(self, params: InflateParams, points):
+        p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        rad = np.empty(len(p), np.float64)
+        idx = np.empty(len(p), np.uint32)
+        d2 = np.empty(len(p), np.float64)
+        _chk(lib().pct_inflate_batch(self._h, C.byref(params), _ptr(p), len(p), _ptr(rad), _ptr(idx), _ptr(d2)))
+        return rad, idx, d2
+
+    def bezier_check(self, params: InflateParams, polycoef, seg_time, orders, t_start, stop_time, dt=0.02, cap=4096):
+        coef = np.ascontiguousarray(polycoef, np.float64)
+        st = np.ascontiguousarray(seg_time, np.float64)
+        od = np.ascontiguousarray(orders, np.int32)
+        traj = BezierTraj(coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[1], st.ctypes.data_as(C.POINTER(C.c_double)),
+                          od.ctypes.data_as(C.POINTER(C.c_int32)), len(st))
+        pos = np.zeros((cap, 3), np.float64)
+        rad = np.zeros(cap, np.float64)
+        d2 = np.zeros(cap, np.float64)
+        idx = np.zeros(cap, np.uint32)
+        fh, ns = C.c_int64(), C.c_int64()
+        _chk(lib().pct_bezier_check(self._h, C.byref(traj), C.byref(params), float(t_start), float(stop_time), float(dt),
+                                    C.byref(fh), C.byref(ns), cap, _ptr(pos), _ptr(rad), _ptr(d2), _ptr(idx)))
+        n = min(ns.value, cap)
+        return dict(first_hit=fh.value, n=ns.value, pos=pos[:n], radius=rad[:n], d2=d2[:n], idx=idx[:n])
+
+    # device-buffer variants: raw pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle
+    def nn_device(self, q_ptr: int, Q: int, idx_ptr: int, d2_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
+        _chk(lib().pct_nn_batch_dev(self._h, algo, q_ptr, int(Q), idx_ptr, d2_ptr, stream))
+
+    def radius_count_device(self, q_ptr: int, r_ptr: int, Q: int, cnt_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
+        _chk(lib().pct_radius_count_batch_dev(self._h, algo, q_ptr, r_ptr, int(Q), cnt_ptr, stream))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().pct_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_work_counters(self, on: bool):
+        _chk(lib().pct_set_work_counters(self._h, int(bool(on))))
+
+    def last_work(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _chk(lib().pct_last_work(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+
+class NNPlan:
+    """hipGraph-captured fixed-shape NN batch (config C5)."""
+
+    def __init__(self, cloud: Cloud, Q: int, algo: int = ALGO_AUTO):
+        self._h = C.c_void_p()
+        self.Q = int(Q)
+        self._cloud = cloud
+        _chk(lib().pct_plan_create_nn(cloud.handle, algo, self.Q, C.byref(self._h)))
+
+    def run(self, queries):
+        q = np.ascontiguousarray(queries, np.float32).reshape(self.Q, 3)
+        idx = np.empty(self.Q, np.uint32)
+        d2 = np.empty(self.Q, np.float64)
+        _chk(lib().pct_plan_run(self._h, _ptr(q), _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().pct_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
