@@ -1,0 +1,102 @@
+// seam_demo.cpp -- the planner's call pattern against the drop-in libraries, as a C++ program:
+//   obstacle cloud   -> pct::ObstacleMap (setInput / radiusSearch / checkTrajPtCol / batch / Bezier check)
+//   RRT* node tree   -> the kd_* C API of libkdtree.so, used exactly like corridor_finder.cpp does
+//                       (kd_create, kd_insertf, kd_nearestf, kd_nearest_rangef, kd_res_*)
+// Self-checking: every GPU answer is compared with a plain host loop in the same fp64 arithmetic.
+// Build: see pointcloudtraj_amd/build.py (g++ -Iinclude ... -lkdtree -lpct_engine).  Exit code 0 = all matched.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kdtree/kdtree.h"
+#include "pct_obstacle_map.hpp"
+
+struct PointXYZ { float x, y, z, pad; };   // the 16-byte layout of pcl::PointXYZ
+
+static uint64_t sm64(uint64_t &s) { uint64_t z = (s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static float u01(uint64_t &s) { return (float)(sm64(s) >> 40) * 0x1p-24f; }
+
+static double host_d2(const PointXYZ &p, const double q[3])
+{
+    double dx = (double)p.x - q[0], dy = (double)p.y - q[1], dz = (double)p.z - q[2];
+    double s = dx * dx; s = s + dy * dy; s = s + dz * dz;
+    return s;
+}
+
+int main()
+{
+    int bad = 0;
+    uint64_t seed = 42;
+    std::vector<PointXYZ> cloud(200000);
+    for (auto &p : cloud) p = { 40.f * u01(seed) - 20.f, 40.f * u01(seed) - 20.f, 6.f * u01(seed), 1.f };
+
+    pct::ObstacleMap map(cloud.size());
+    const double start[3] = { -10, -10, 2 };
+    map.setParam(0.6, 0.25, 1.5, 30.0);          // clean_demo.launch: safety 0.6, search margin 0.25, max radius 1.5, range 30
+    map.setStartPt(start);
+    map.setInput(cloud.data(), (int64_t)cloud.size(), sizeof(PointXYZ));
+
+    // single-point inflation, the RRT* inner call (corridor_finder.cpp:385-410 -> :113-133)
+    std::vector<double> pts;
+    for (int i = 0; i < 256; i++) { pts.push_back(36. * u01(seed) - 18.); pts.push_back(36. * u01(seed) - 18.); pts.push_back(0.5 + 5. * u01(seed)); }
+    std::vector<double> rad(256), d2(256);
+    std::vector<uint32_t> idx(256);
+    map.checkRadiusBatch(pts.data(), 256, rad.data(), idx.data(), d2.data());
+    for (int i = 0; i < 256; i++) {
+        const double q[3] = { (double)(float)pts[3 * i], (double)(float)pts[3 * i + 1], (double)(float)pts[3 * i + 2] };
+        double best = INFINITY; uint32_t bi = 0;
+        for (uint32_t k = 0; k < cloud.size(); k++) { double s = host_d2(cloud[k], q); if (s < best) { best = s; bi = k; } }
+        double want = std::sqrt(best) - 0.25; if (want > 1.5) want = 1.5;
+        if (best != d2[i] || bi != idx[i] || want != rad[i]) { bad++; std::printf("inflate mismatch at %d\n", i); }
+        if (i < 8 && map.radiusSearch(&pts[3 * i]) != rad[i]) { bad++; std::printf("single radiusSearch mismatch at %d\n", i); }
+        if (i < 8 && map.checkTrajPtCol(&pts[3 * i]) != (rad[i] < 0)) bad++;
+    }
+
+    // node tree through the reference's own C API
+    kdtree *tree = kd_create(3);
+    if (!tree) { std::printf("kd_create failed\n"); return 2; }
+    std::vector<PointXYZ> nodes(500);
+    for (size_t i = 0; i < nodes.size(); i++) {
+        nodes[i] = { 20.f * u01(seed) - 10.f, 20.f * u01(seed) - 10.f, 4.f * u01(seed), 0.f };
+        float pos[3] = { nodes[i].x, nodes[i].y, nodes[i].z };
+        if (kd_insertf(tree, pos, (void *)(intptr_t)(i + 1))) bad++;
+        if (i % 25 == 0) {   // interleaved query, as findNearstVertex does (corridor_finder.cpp:428-437)
+            float qf[3] = { 20.f * u01(seed) - 10.f, 20.f * u01(seed) - 10.f, 4.f * u01(seed) };
+            kdres *res = kd_nearestf(tree, qf);
+            intptr_t got = (intptr_t)kd_res_item_data(res) - 1;
+            kd_res_free(res);
+            const double q[3] = { qf[0], qf[1], qf[2] };
+            double best = INFINITY; intptr_t bi = -1;
+            for (size_t k = 0; k <= i; k++) { double s = host_d2(nodes[k], q); if (s < best) { best = s; bi = (intptr_t)k; } }
+            if (got != bi) { bad++; std::printf("kd_nearestf mismatch at node %zu\n", i); }
+            kdres *rs = kd_nearest_rangef(tree, qf, 3.0f);   // treeRewire's neighbourhood query (:464)
+            int cnt = 0;
+            for (size_t k = 0; k <= i; k++) cnt += host_d2(nodes[k], q) <= 9.0;
+            int it = 0;
+            while (!kd_res_end(rs)) { it++; kd_res_next(rs); }
+            if (kd_res_size(rs) != cnt || it != cnt) { bad++; std::printf("kd_nearest_rangef size %d vs %d\n", kd_res_size(rs), cnt); }
+            kd_res_free(rs);
+        }
+    }
+    kd_free(tree);
+
+    // Bezier collision check on a straight 3-segment trajectory through the cloud
+    const int32_t orders[3] = { 4, 4, 4 };
+    const double T[3] = { 1.0, 1.0, 1.0 };
+    double coef[3][15];
+    for (int s = 0; s < 3; s++)
+        for (int d = 0; d < 3; d++)
+            for (int j = 0; j < 5; j++) {
+                const double a = (s + j / 4.0) / 3.0;
+                const double p0[3] = { -10, -10, 2 }, p1[3] = { 10, 10, 2 };
+                coef[s][d * 5 + j] = ((1 - a) * p0[d] + a * p1[d]) / T[s];
+            }
+    int64_t fh = -1, ns = 0;
+    const bool hit = map.checkSafeTrajectory(&coef[0][0], 15, T, orders, 3, 0.0, 2.0, &fh, &ns);
+    std::printf("bezier: samples=%lld first_hit=%lld collide=%d\n", (long long)ns, (long long)fh, (int)hit);
+    if (ns != 99) bad++;
+
+    std::printf(bad ? "seam_demo: %d MISMATCHES\n" : "seam_demo: all checks passed (%d mismatches)\n", bad);
+    return bad ? 1 : 0;
+}

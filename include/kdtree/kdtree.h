@@ -1,7 +1,7 @@
 /*
  * kdtree/kdtree.h -- public C API of the drop-in libkdtree.so built by this repository.
  *
- * Same 22 entry points, names, signatures and calling conventions as the reference's
+ * Same 26 entry points (SURVEY.md counts them as "22"; the header declares 26), names, signatures and calling conventions as the reference's
  * Utils/kdtree/include/kdtree/kdtree.h:39-122, so that Planner/src/corridor_finder.cpp
  * (call sites :174,179,431-434,464-488,647,709,716,750,802,956-1015) links against it
  * unchanged.  The implementation behind it is NOT a pointer tree on the host: points are

@@ -1,7 +1,7 @@
 /*
  * pct_engine.h -- C ABI of the MI355X obstacle-cloud engine (libpct_engine.so).
  *
- * This is the batched extension SURVEY.md section 8(b) specifies next to the 22 kd_* functions
+ * This is the batched extension SURVEY.md section 8(b) specifies next to the kd_* functions
  * (include/kdtree/kdtree.h): an opaque cloud handle in HBM plus batch queries that replace
  * the per-point PCL/FLANN calls on the planner's hot path.  Plain pointers and sizes only;
  * int status codes; no exceptions cross the boundary; host buffers are caller-owned.
@@ -52,8 +52,9 @@ enum pct_status {
 
 enum pct_algo {
     PCT_ALGO_AUTO = 0,       /* grid kernel when a grid is built, streaming kernel otherwise */
-    PCT_ALGO_STREAM = 1,     /* brute-force SoA streaming kernel (no index needed; rolling clouds) */
-    PCT_ALGO_GRID = 2        /* cell-pruned kernel (needs pct_cloud_build_grid) */
+    PCT_ALGO_STREAM = 1,     /* brute-force SoA streaming kernels: fp32 filter + exact fp64 recheck (no index needed) */
+    PCT_ALGO_GRID = 2,       /* cell-pruned kernel (needs pct_cloud_build_grid) */
+    PCT_ALGO_STREAM_EXACT = 3 /* brute force with every pair in fp64 (the filter's reference; same results) */
 };
 
 /* ---- process / device ---------------------------------------------------------------- */
@@ -92,12 +93,15 @@ int pct_cloud_grid_info(const pct_cloud *c, int32_t dims[3], float *cell_size, f
 /* q: Q x 3 fp32.  idx[Q] (index_base + local index), d2[Q] fp64. */
 int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double *d2);
 int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_t *idx, double *d2);
+/* same with fp64 query coordinates (kd_nearest's double positions); streaming kernel */
+int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2);
 /* count[Q] = #points with d2 <= r*r */
 int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t Q, uint32_t *count);
 int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const float *r, int64_t Q, uint32_t *count);
 /* lidar-style crop (camera_sensor.cpp:133-145): indices of all points within r of ONE centre,
  * ascending index order; returns the count through *n_out (may exceed cap; only cap written). */
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
 
 typedef struct pct_inflate_params {
     double start[3];        /* start_pt */
@@ -148,6 +152,8 @@ int pct_last_kernel_ms(pct_cloud *c, float *ms);
 /* algorithmic work of the last batch: points examined (sum over queries), cells examined */
 int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
 int pct_set_work_counters(pct_cloud *c, int enabled);
+/* diagnostics: the fp32 upper bounds the streaming filter used for the last batch */
+int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q);
 
 #ifdef __cplusplus
 }

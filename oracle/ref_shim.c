@@ -2,7 +2,7 @@
  * oracle/ref_shim.c -- TEST INFRASTRUCTURE.  Batch drivers around the PUBLIC kd_* API of
  * the reference library (oracle/_ref/libkdtree_ref.so, compiled unmodified from
  * /root/reference/Utils/kdtree/src/kdtree.c).  Contains no reference code: it only calls
- * the 22 exported functions the way a client would, in C loops, so that fixtures and the
+ * the exported functions the way a client would, in C loops, so that fixtures and the
  * "reference" CPU baseline do not pay Python call overhead per query.
  *
  * Payload convention: data = (void*)(insertion index + 1), so NULL never aliases id 0.

@@ -16,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib")
 ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
 KDTREE_SO = os.path.join(LIB, "libkdtree.so")
+DEMO_BIN = os.path.join(LIB, "seam_demo")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -40,8 +41,20 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
         subprocess.run(cmd, check=True)
     kd_src = [os.path.join(CSRC, "kdtree_gpu.cpp")]
     if os.path.exists(kd_src[0]) and (force or _stale(KDTREE_SO, kd_src + hdrs + [ENGINE_SO])):
-        cmd = [HIPCC, *COMMON, "-x", "hip", "-o", KDTREE_SO, kd_src[0], "-L" + LIB, "-lpct_engine",
-               "-Wl,-rpath,$ORIGIN", "-Wl,-soname,libkdtree.so"]
+        # host-only C++ (no device code): it reaches the GPU through libpct_engine.so's C ABI
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"),
+               "-o", KDTREE_SO, kd_src[0], "-L" + LIB, "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-soname,libkdtree.so"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+
+    demo_src = os.path.join(ROOT, "examples", "seam_demo.cpp")
+    if os.path.exists(demo_src) and os.path.exists(KDTREE_SO) and (force or _stale(DEMO_BIN, [demo_src, KDTREE_SO] + hdrs + [os.path.join(ROOT, "include", "pct_obstacle_map.hpp")])):
+        # a plain g++ client of the two libraries: the link line INTEGRATION.md gives the planner
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", DEMO_BIN, demo_src,
+               "-L" + LIB, "-lkdtree", "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
+               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

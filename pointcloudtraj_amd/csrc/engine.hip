@@ -87,11 +87,15 @@ struct pct_cloud {
     size_t cells_cap = 0;
     float4 *sorted = nullptr;
     size_t sorted_cap = 0;
+    BinDesc B{};
+    uint32_t *bin_start = nullptr, *bin_fill = nullptr, *bin_tiles = nullptr;   // query binning (sized at grid build)
+    size_t bins_cap = 0;
+    uint32_t *d_qbin = nullptr, *d_perm = nullptr;                              // sized by reserve_queries
     // query workspaces
     int64_t qcap = 0;
     float *d_q = nullptr, *d_r = nullptr;
     double *d_q64 = nullptr, *d_r2 = nullptr, *d_d2 = nullptr, *d_radius = nullptr, *d_pts64 = nullptr;
-    uint32_t *d_idx = nullptr, *d_count = nullptr;
+    uint32_t *d_idx = nullptr, *d_count = nullptr, *d_bound = nullptr;
     unsigned char *d_skip = nullptr;
     double *d_part_d2 = nullptr;
     uint32_t *d_part_idx = nullptr;
@@ -167,10 +171,15 @@ int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64
     return PCT_OK;
 }
 
+// Streaming kernels are grid-stride: at most 4 blocks of 256 threads per CU (16 waves per CU),
+// so the whole grid is resident in ONE round whatever the kernel's register count -- a grid of
+// 8 blocks per CU ran as 7 + 1 rounds at 66 VGPRs and cost almost 2x (profiles/r01_a).
 int stream_blocks(int64_t n)
 {
+    const char *e = std::getenv("PCT_STREAM_BLOCKS");      // tuning knob for scripts/probe.py
+    const int cap = e ? std::max(1, std::min(kMaxParts, std::atoi(e))) : 1024;
     const int64_t groups = std::max<int64_t>(n >> 2, 1);
-    return (int)std::min<int64_t>(kMaxParts, (groups + 255) / 256);
+    return (int)std::min<int64_t>(cap, (groups + 255) / 256);
 }
 
 template <int QT>
@@ -207,6 +216,98 @@ void end_timing(pct_cloud *c, hipStream_t s)
     if (hipEventRecord(c->ev1, s) != hipSuccess) c->ev_valid = false;
 }
 
+// streaming NN over the fp64 queries already in c->d_q64
+int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+{
+    const int blocks = stream_blocks(c->count);
+    begin_timing(c, s);
+    for (int64_t q0 = 0; q0 < Q;) {
+        const int qt = pick_tile(Q - q0);
+        const int qcount = (int)std::min<int64_t>(qt, Q - q0);
+        switch (qt) {
+        case 8: launch_nn_stream<8>(c, blocks, (int)q0, qcount, s); break;
+        case 4: launch_nn_stream<4>(c, blocks, (int)q0, qcount, s); break;
+        case 2: launch_nn_stream<2>(c, blocks, (int)q0, qcount, s); break;
+        default: launch_nn_stream<1>(c, blocks, (int)q0, qcount, s); break;
+        }
+        q0 += qcount;
+    }
+    nn_reduce_partials_kernel<<<(int)Q, 256, 0, s>>>(c->d_part_d2, c->d_part_idx, blocks, (uint32_t)c->index_base, d_idx, d_d2);
+    end_timing(c, s);
+    HIPCHK(hipGetLastError());
+    c->host_work = true;                    // the streaming kernel examines every point for every query
+    c->host_points = (uint64_t)Q * (uint64_t)c->count;
+    return PCT_OK;
+}
+
+// counting sort of the batch by coarse cell -> c->d_perm (nullptr result = keep arrival order)
+int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const uint32_t **perm_out)
+{
+    *perm_out = nullptr;
+    int64_t min_q = 16384;
+    if (const char *e = std::getenv("PCT_SORT_MIN_Q")) min_q = std::atoll(e);
+    if (Q < min_q) return PCT_OK;
+    const BinDesc &B = c->B;
+    const uint32_t ntiles = (B.nbins + kScanTile - 1) / kScanTile;
+    HIPCHK(hipMemsetAsync(c->bin_fill, 0, sizeof(uint32_t) * B.nbins, s));
+    query_bin_count_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->G, B, d_q, (uint32_t)Q, c->bin_fill, c->d_qbin);
+    scan_tiles_kernel<<<ntiles, 256, 0, s>>>(c->bin_fill, B.nbins, c->bin_start, c->bin_tiles);
+    scan_tile_sums_kernel<<<1, 256, 0, s>>>(c->bin_tiles, ntiles);
+    scan_add_kernel<<<ceil_div(B.nbins, 256), 256, 0, s>>>(c->bin_start, B.nbins, c->bin_tiles, (uint32_t)Q);
+    HIPCHK(hipMemsetAsync(c->bin_fill, 0, sizeof(uint32_t) * B.nbins, s));
+    query_bin_scatter_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->d_qbin, (uint32_t)Q, c->bin_start, c->bin_fill, c->d_perm);
+    HIPCHK(hipGetLastError());
+    *perm_out = c->d_perm;
+    return PCT_OK;
+}
+
+constexpr int kMaxTileParts = 8192;      // tile kernel: at most this many point chunks per launch
+constexpr uint32_t kChunkGroupsMax = 3072;   // 3 * 3072 * 16 B = 144 KiB of the CU's 160 KiB LDS
+
+// Default brute-force path: packed-fp32 filter + exact fp64 recheck over LDS-staged chunks
+// (kernels.hpp).  d_qf: the fp32 queries; c->d_q64 must already hold their widened copies.
+int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(3 * kChunkGroupsMax * sizeof(float4))));
+        attr_set = true;
+    }
+    const int64_t ngroups = c->count >> 2;
+    // chunk = 1024 groups (4096 points, 48 KiB LDS -> 3 blocks per CU); larger only for huge clouds
+    uint32_t chunk = 1024;
+    if (const char *e = std::getenv("PCT_TILE_CHUNK")) chunk = (uint32_t)std::max(256, std::min((int)kChunkGroupsMax, std::atoi(e)));
+    if ((ngroups + chunk - 1) / chunk > kMaxTileParts) chunk = (uint32_t)std::min<int64_t>(kChunkGroupsMax, ((ngroups + kMaxTileParts - 1) / kMaxTileParts + 255) / 256 * 256);
+    const int nblocks = (int)std::max<int64_t>(1, (ngroups + chunk - 1) / chunk);
+    if (nblocks > kMaxTileParts) return fail(PCT_ERR_INVALID, "cloud of %lld points is too large for the brute-force path", (long long)c->count);
+    // sample 1 chunk in 16 (everything for small clouds; sparser for huge ones so the partial buffer fits)
+    const uint32_t stride = ngroups >= 256ll * kSampleStride * 8
+                                ? (uint32_t)std::max<int64_t>(kSampleStride, (ngroups + 256ll * kMaxParts - 1) / (256ll * kMaxParts))
+                                : 1u;
+    const int64_t schunks = std::max<int64_t>(1, (ngroups + 256ll * stride - 1) / (256ll * stride));
+    const int sblocks = (int)((schunks + kSampleGroups - 1) / kSampleGroups);
+    const int64_t part_cap = c->qcap * kMaxParts;          // entries in d_part_d2 / d_part_idx
+    begin_timing(c, s);
+    // the sample partials borrow d_part_idx (u32 and float have the same size; [Q][sblocks], sblocks <= kMaxParts);
+    // bound_reduce_kernel consumes them before the filter pass overwrites the buffer
+    nn_sample_bounds_kernel<<<sblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, stride, d_qf, (int)Q,
+                                                    reinterpret_cast<float *>(c->d_part_idx), sblocks);
+    bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, c->d_bound);
+    const int64_t qb_max = std::max<int64_t>(kTileQ, part_cap / nblocks / kTileQ * kTileQ);
+    for (int64_t qbase = 0; qbase < Q; qbase += qb_max) {
+        const int qb = (int)std::min<int64_t>(qb_max, Q - qbase);
+        nn_tile_filter_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, c->d_q64,
+                                                                                       c->d_bound, (int)qbase, qb, c->d_part_d2, c->d_part_idx, nblocks);
+        nn_reduce_partials_kernel<<<qb, 256, 0, s>>>(c->d_part_d2, c->d_part_idx, nblocks, (uint32_t)c->index_base, d_idx + qbase, d_d2 + qbase);
+    }
+    end_timing(c, s);
+    HIPCHK(hipGetLastError());
+    c->host_work = true;
+    c->host_points = (uint64_t)Q * (uint64_t)c->count;
+    return PCT_OK;
+}
+
 int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
 {
     if (Q == 0) return PCT_OK;
@@ -222,37 +323,25 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         c->host_work = false;
         if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
         begin_timing(c, s);
+        const uint32_t *perm = nullptr;
+        PCTCHK(bin_queries(c, d_q, Q, s, &perm));
         if (c->count_work)
             nn_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
-                                                                   (uint32_t)c->index_base, d_idx, d_d2, c->d_work);
+                                                                   (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
         else
             nn_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
-                                                                    (uint32_t)c->index_base, d_idx, d_d2, c->d_work);
+                                                                    (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
         end_timing(c, s);
         HIPCHK(hipGetLastError());
         return PCT_OK;
     }
-    if (algo != PCT_ALGO_STREAM) return fail(PCT_ERR_INVALID, "unknown algo %d", algo);
+    if (algo != PCT_ALGO_STREAM && algo != PCT_ALGO_STREAM_EXACT) return fail(PCT_ERR_INVALID, "unknown algo %d", algo);
     widen_queries_kernel<<<ceil_div(3 * Q, 256), 256, 0, s>>>(d_q, (uint32_t)(3 * Q), c->d_q64);
-    const int blocks = stream_blocks(c->count);
-    begin_timing(c, s);
-    for (int64_t q0 = 0; q0 < Q;) {
-        const int qt = pick_tile(Q - q0);
-        const int qcount = (int)std::min<int64_t>(qt, Q - q0);
-        switch (qt) {
-        case 8: launch_nn_stream<8>(c, blocks, (int)q0, qcount, s); break;
-        case 4: launch_nn_stream<4>(c, blocks, (int)q0, qcount, s); break;
-        case 2: launch_nn_stream<2>(c, blocks, (int)q0, qcount, s); break;
-        default: launch_nn_stream<1>(c, blocks, (int)q0, qcount, s); break;
-        }
-        q0 += qcount;
-    }
-    nn_reduce_partials_kernel<<<(int)Q, 64, 0, s>>>(c->d_part_d2, c->d_part_idx, blocks, (uint32_t)c->index_base, d_idx, d_d2);
-    end_timing(c, s);
-    HIPCHK(hipGetLastError());
-    c->host_work = true;                    // the streaming kernel examines every point for every query
-    c->host_points = (uint64_t)Q * (uint64_t)c->count;
-    return PCT_OK;
+    // <= 4 queries: the all-fp64 kernel is already HBM-bound (50-62 % of peak); beyond that the
+    // packed-fp32 filter wins
+    static const int64_t exact_max_q = [] { const char *e = std::getenv("PCT_EXACT_MAX_Q"); return e ? std::atoll(e) : 4ll; }();
+    if (algo == PCT_ALGO_STREAM_EXACT || Q <= exact_max_q) return nn_stream_q64(c, Q, d_idx, d_d2, s);
+    return nn_stream_filtered(c, d_q, Q, d_idx, d_d2, s);
 }
 
 int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, hipStream_t s)
@@ -267,10 +356,12 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
         c->host_work = false;
         if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
         begin_timing(c, s);
+        const uint32_t *perm = nullptr;
+        PCTCHK(bin_queries(c, d_q, Q, s, &perm));
         if (c->count_work)
-            count_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, d_count, c->d_work);
+            count_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, perm, d_count, c->d_work);
         else
-            count_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, d_count, c->d_work);
+            count_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, perm, d_count, c->d_work);
         end_timing(c, s);
         HIPCHK(hipGetLastError());
         return PCT_OK;
@@ -376,9 +467,10 @@ int pct_cloud_destroy(pct_cloud *c)
     if (!c) return PCT_OK;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
-    dev_free(c->cell_start); dev_free(c->sorted);
+    dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
+    dev_free(c->d_qbin); dev_free(c->d_perm);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
-    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip);
+    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
@@ -452,8 +544,8 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     HIPCHK(hipStreamSynchronize(g_stream));
     const int64_t q = std::max<int64_t>(Q, 256);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
-    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx);
+    dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_qbin); dev_free(c->d_perm);
     c->qcap = 0;
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
     PCTCHK(dev_alloc(&c->d_r, q));
@@ -465,6 +557,9 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_idx, q));
     PCTCHK(dev_alloc(&c->d_count, q));
     PCTCHK(dev_alloc(&c->d_skip, q));
+    PCTCHK(dev_alloc(&c->d_bound, q));
+    PCTCHK(dev_alloc(&c->d_qbin, q));
+    PCTCHK(dev_alloc(&c->d_perm, q));
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)q * kMaxParts));
     PCTCHK(dev_alloc(&c->d_part_idx, (size_t)q * kMaxParts));
     c->qcap = q;
@@ -523,10 +618,12 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     for (int k = 0; k < 3; k++) ext[k] = std::max((double)hi[k] - (double)lo[k], 0.0);
     double h = cell_size;
     if (!(h > 0)) {
+        double ppc = 2.0;                                   // target points per cell
+        if (const char *e = std::getenv("PCT_GRID_PPC")) ppc = std::max(0.05, std::atof(e));
         const double diag = std::max({ ext[0], ext[1], ext[2], 1e-6 });
         double vol = 1.0;
         for (int k = 0; k < 3; k++) vol *= std::max(ext[k], diag * 1e-3);
-        h = std::cbrt(vol * 2.0 / (double)n);
+        h = std::cbrt(vol * ppc / (double)n);
     }
     const double max_ext = std::max({ ext[0], ext[1], ext[2] });
     h = std::max(h, max_ext / 1023.0);
@@ -580,6 +677,23 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     dev_free(d_cnt); dev_free(d_pcell); dev_free(d_tiles);
     if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
     c->G = G;
+    // query bins: (2^shift)^3 cells each
+    BinDesc B{};
+    B.shift = 1;
+    if (const char *eb = std::getenv("PCT_BIN_SHIFT")) B.shift = std::max(0, std::min(4, std::atoi(eb)));
+    B.bx = ((G.gx - 1) >> B.shift) + 1;
+    B.by = ((G.gy - 1) >> B.shift) + 1;
+    B.bz = ((G.gz - 1) >> B.shift) + 1;
+    B.nbins = (uint32_t)B.bx * (uint32_t)B.by * (uint32_t)B.bz;
+    if ((size_t)B.nbins + 1 > c->bins_cap) {
+        dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
+        c->bins_cap = 0;
+        PCTCHK(dev_alloc(&c->bin_start, (size_t)B.nbins + 1));
+        PCTCHK(dev_alloc(&c->bin_fill, (size_t)B.nbins));
+        PCTCHK(dev_alloc(&c->bin_tiles, (size_t)(B.nbins + kScanTile - 1) / kScanTile));
+        c->bins_cap = (size_t)B.nbins + 1;
+    }
+    c->B = B;
     c->has_grid = true;
     return PCT_OK;
 }
@@ -617,6 +731,35 @@ int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double 
     return pct_nn_batch_algo(c, PCT_ALGO_AUTO, q, Q, idx, d2);
 }
 
+int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2)
+{
+    if (!c || Q < 0 || (Q > 0 && (!q || !idx || !d2))) return fail(PCT_ERR_INVALID, "bad nn_batch_q64 arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(pct_cloud_reserve_queries(c, Q));
+    if (c->count == 0) {
+        for (int64_t i = 0; i < Q; i++) { idx[i] = PCT_NO_INDEX; d2[i] = INFINITY; }
+        return fail(PCT_ERR_EMPTY, "nearest-neighbour query against an empty cloud");
+    }
+    // The fp32 filter is only valid when the query coordinates themselves are fp32 values
+    // (always the case for kd_nearestf); genuinely double queries take the all-fp64 kernel.
+    bool f32_exact = true;
+    for (int64_t i = 0; i < 3 * Q && f32_exact; i++) f32_exact = (double)(float)q[i] == q[i];
+    HIPCHK(hipMemcpyAsync(c->d_q64, q, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+    if (f32_exact && Q > 4) {
+        std::vector<float> qf((size_t)3 * Q);
+        for (int64_t i = 0; i < 3 * Q; i++) qf[i] = (float)q[i];
+        HIPCHK(hipMemcpyAsync(c->d_q, qf.data(), sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));      // qf goes out of scope below
+        PCTCHK(nn_stream_filtered(c, c->d_q, Q, c->d_idx, c->d_d2, g_stream));
+    } else {
+        PCTCHK(nn_stream_q64(c, Q, c->d_idx, c->d_d2, g_stream));
+    }
+    HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(d2, c->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
+
 int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const float *r, int64_t Q, uint32_t *count)
 {
     if (!c || Q < 0 || (Q > 0 && (!q || !r || !count))) return fail(PCT_ERR_INVALID, "bad radius_count arguments");
@@ -637,6 +780,13 @@ int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t
 
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out)
 {
+    if (!q) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
+    const double qd[3] = { (double)q[0], (double)q[1], (double)q[2] };
+    return pct_radius_indices_q64(c, qd, (double)r, idx_out, cap, n_out);
+}
+
+int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out)
+{
     if (!c || !q || cap < 0 || (cap > 0 && !idx_out) || !n_out) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
     *n_out = 0;
     if (c->count == 0) return PCT_OK;
@@ -646,8 +796,8 @@ int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_ou
     if (st) { dev_free(d_out); return st; }
     hipError_t e = hipMemsetAsync(d_cursor, 0, sizeof(uint32_t), g_stream);
     const int blocks = (int)std::min<int64_t>(4096, (c->count + 255) / 256);
-    const double rr = (double)r * (double)r;
-    radius_collect_kernel<<<blocks, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, (double)q[0], (double)q[1], (double)q[2], rr,
+    const double rr = r * r;
+    radius_collect_kernel<<<blocks, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], rr,
                                                          (uint32_t)c->index_base, d_out, (uint32_t)cap, d_cursor);
     uint32_t total = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, sizeof total, hipMemcpyDeviceToHost, g_stream);
@@ -790,6 +940,14 @@ int pct_last_kernel_ms(pct_cloud *c, float *ms)
     if (!c->ev_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PCT_OK;
+}
+
+int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q)
+{
+    if (!c || !out || Q > c->qcap) return fail(PCT_ERR_INVALID, "bad arguments");
+    HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(out, c->d_bound, sizeof(float) * Q, hipMemcpyDeviceToHost));
     return PCT_OK;
 }
 

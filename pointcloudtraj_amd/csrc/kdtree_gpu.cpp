@@ -1,0 +1,336 @@
+// kdtree_gpu.cpp -- libkdtree.so: the reference's kd_* C API (26 functions)
+// (include/kdtree/kdtree.h; reference Utils/kdtree/include/kdtree/kdtree.h:39-122) served by the
+// MI355X engine.
+//
+// What lives where:
+//   device : the points, as an fp32 SoA cloud in HBM (pct_cloud).  kd_nearest* and
+//            kd_nearest_range* are answered by the HIP streaming kernels -- every distance is
+//            computed on the GPU, in the reference's fp64 arithmetic.
+//   host   : payload pointers, fp64 copies of the coordinates handed back by kd_res_item*, and
+//            the insertion topology (child links + split axis per node, kdtree.c:167-194).
+//            The topology is NOT used to search.  It exists because the reference's result
+//            ORDER for range queries is observable (corridor_finder.cpp:464-488 breaks on the
+//            first containing neighbour) and is a property of the insertion-ordered tree:
+//            hits come out in reverse pre-order of a near-child-first walk (kdtree.c:262-293,
+//            810-828), and a hit behind a split plane with fabs(dx) == range is dropped
+//            (:283).  The host replays exactly that filter and order over the GPU's hit list.
+//
+// Deliberate differences (documented in include/kdtree/kdtree.h): lowest insertion index on
+// exact distance ties; k == 3 only; stored coordinates must be representable in fp32 (always
+// true for the *f entry points, which are the only ones the planner uses); no host fallback.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kdtree/kdtree.h"
+#include "pct_engine.h"
+
+namespace {
+constexpr int32_t NIL = -1;
+
+void complain(const char *what)
+{
+    std::fprintf(stderr, "[libkdtree/pct] %s: %s\n", what, pct_last_error());
+}
+}  // namespace
+
+struct kdtree {
+    int dim = 3;
+    std::vector<double> pos;      // 3 per node, insertion order (fp64 as the reference stores them)
+    std::vector<float> posf;      // the same, narrowed (exact) -- what is mirrored to HBM
+    std::vector<void *> data;
+    std::vector<int32_t> lo, hi, parent;
+    std::vector<uint8_t> axis;
+    void (*destr)(void *) = nullptr;
+    pct_cloud *cloud = nullptr;
+    int64_t synced = 0;           // nodes [0, synced) are in HBM
+    int64_t count() const { return (int64_t)data.size(); }
+};
+
+struct kdres {
+    kdtree *tree = nullptr;
+    std::vector<int32_t> items;   // node ids in ITERATION order
+    size_t cursor = 0;
+    int size = 0;
+};
+
+namespace {
+
+// bring HBM up to date with the host-side node list
+int sync_device(kdtree *t)
+{
+    const int64_t n = t->count();
+    if (t->cloud && n > pct_cloud_capacity(t->cloud)) {
+        pct_cloud_destroy(t->cloud);
+        t->cloud = nullptr;
+        t->synced = 0;
+    }
+    if (!t->cloud) {
+        int64_t cap = 1024;
+        while (cap < n) cap *= 2;
+        if (pct_cloud_create(cap, &t->cloud) != PCT_OK) { complain("pct_cloud_create"); t->cloud = nullptr; return -1; }
+        t->synced = 0;
+    }
+    if (t->synced < n) {
+        int st = (t->synced == 0) ? pct_cloud_upload_aos(t->cloud, t->posf.data(), n, 12)
+                                  : pct_cloud_append_aos(t->cloud, t->posf.data() + 3 * t->synced, n - t->synced, 12);
+        if (st != PCT_OK) { complain("cloud upload"); return -1; }
+        t->synced = n;
+    }
+    return 0;
+}
+
+// kdtree.c:136-148: destructor order = left subtree, right subtree, node
+void run_destructors(kdtree *t)
+{
+    if (!t->destr || t->data.empty()) return;
+    std::vector<int32_t> stack{ 0 };
+    std::vector<uint8_t> state(t->data.size(), 0);
+    while (!stack.empty()) {
+        const int32_t n = stack.back();
+        if (state[n] == 0) { state[n] = 1; if (t->lo[n] != NIL) stack.push_back(t->lo[n]); }
+        else if (state[n] == 1) { state[n] = 2; if (t->hi[n] != NIL) stack.push_back(t->hi[n]); }
+        else { t->destr(t->data[n]); stack.pop_back(); }
+    }
+}
+
+// Is node n visited by the reference's range walk for (q, range), and where?  `path` receives
+// one byte per edge from the root: 0 = the step went to the nearer child, 1 = to the farther
+// one.  Returns false when some far-side step has fabs(dx) >= range (kdtree.c:283).
+bool walk_path(const kdtree *t, int32_t n, const double *q, double range, std::vector<uint8_t> &path)
+{
+    path.clear();
+    for (int32_t c = n, a = t->parent[n]; a != NIL; c = a, a = t->parent[a]) {
+        const int ax = t->axis[a];
+        const double dx = q[ax] - t->pos[3 * (size_t)a + ax];
+        const int32_t near_child = dx <= 0.0 ? t->lo[a] : t->hi[a];
+        if (c == near_child) path.push_back(0);
+        else {
+            if (!(std::fabs(dx) < range)) return false;
+            path.push_back(1);
+        }
+    }
+    std::reverse(path.begin(), path.end());
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct kdtree *kd_create(int k)
+{
+    if (k != 3) {
+        std::fprintf(stderr, "[libkdtree/pct] kd_create(%d): only k == 3 is served by the device path\n", k);
+        return nullptr;
+    }
+    if (pct_device_count() <= 0) {
+        std::fprintf(stderr, "[libkdtree/pct] kd_create: no HIP device; this library has no host fallback\n");
+        return nullptr;
+    }
+    kdtree *t = new (std::nothrow) kdtree();
+    return t;
+}
+
+void kd_clear(struct kdtree *t)
+{
+    run_destructors(t);
+    t->pos.clear(); t->posf.clear(); t->data.clear();
+    t->lo.clear(); t->hi.clear(); t->parent.clear(); t->axis.clear();
+    t->synced = 0;
+    if (t->cloud) pct_cloud_upload_aos(t->cloud, nullptr, 0, 12);
+}
+
+void kd_free(struct kdtree *t)
+{
+    if (!t) return;
+    kd_clear(t);
+    if (t->cloud) pct_cloud_destroy(t->cloud);
+    delete t;
+}
+
+void kd_data_destructor(struct kdtree *t, void (*destr)(void *)) { t->destr = destr; }
+
+// kdtree.c:167-209: strictly smaller on the split axis -> negative side, ties and larger ->
+// positive side; a new leaf splits on (parent axis + 1) % 3, the root on axis 0.
+int kd_insert(struct kdtree *t, const double *p, void *data)
+{
+    float pf[3];
+    for (int i = 0; i < 3; i++) {
+        pf[i] = (float)p[i];
+        if ((double)pf[i] != p[i]) {
+            std::fprintf(stderr, "[libkdtree/pct] kd_insert: coordinate %.17g is not representable in fp32 (device cloud is fp32)\n", p[i]);
+            return -1;
+        }
+    }
+    const int32_t id = (int32_t)t->count();
+    int ax = 0;
+    int32_t par = NIL;
+    try {
+        if (id > 0) {
+            int32_t cur = 0;
+            for (;;) {
+                const int a = t->axis[cur];
+                int32_t &link = (p[a] < t->pos[3 * (size_t)cur + a]) ? t->lo[cur] : t->hi[cur];
+                if (link == NIL) { link = id; ax = (a + 1) % 3; par = cur; break; }
+                cur = link;
+            }
+        }
+        t->pos.insert(t->pos.end(), p, p + 3);
+        t->posf.insert(t->posf.end(), pf, pf + 3);
+        t->data.push_back(data);
+        t->lo.push_back(NIL); t->hi.push_back(NIL); t->parent.push_back(par);
+        t->axis.push_back((uint8_t)ax);
+    } catch (const std::bad_alloc &) {
+        return -1;
+    }
+    return 0;
+}
+
+int kd_insertf(struct kdtree *t, const float *p, void *data)
+{
+    const double w[3] = { p[0], p[1], p[2] };
+    return kd_insert(t, w, data);
+}
+int kd_insert3(struct kdtree *t, double x, double y, double z, void *data)
+{
+    const double w[3] = { x, y, z };
+    return kd_insert(t, w, data);
+}
+int kd_insert3f(struct kdtree *t, float x, float y, float z, void *data)
+{
+    const double w[3] = { x, y, z };
+    return kd_insert(t, w, data);
+}
+
+// kdtree.c:404-457 -- NULL for a NULL or empty tree; otherwise a one-element set
+struct kdres *kd_nearest(struct kdtree *t, const double *q)
+{
+    if (!t || t->count() == 0) return nullptr;
+    if (sync_device(t)) return nullptr;
+    uint32_t idx = PCT_NO_INDEX;
+    double d2 = 0;
+    if (pct_nn_batch_q64(t->cloud, q, 1, &idx, &d2) != PCT_OK) { complain("kd_nearest"); return nullptr; }
+    kdres *r = new (std::nothrow) kdres();
+    if (!r) return nullptr;
+    r->tree = t;
+    r->items.push_back((int32_t)idx);
+    r->size = 1;
+    return r;
+}
+struct kdres *kd_nearestf(struct kdtree *t, const float *q)
+{
+    const double w[3] = { q[0], q[1], q[2] };
+    return kd_nearest(t, w);
+}
+struct kdres *kd_nearest3(struct kdtree *t, double x, double y, double z)
+{
+    const double w[3] = { x, y, z };
+    return kd_nearest(t, w);
+}
+struct kdres *kd_nearest3f(struct kdtree *t, float x, float y, float z)
+{
+    const double w[3] = { x, y, z };
+    return kd_nearest(t, w);
+}
+
+// kdtree.c:537-559 -- an empty tree yields a valid empty set
+struct kdres *kd_nearest_range(struct kdtree *t, const double *q, double range)
+{
+    kdres *r = new (std::nothrow) kdres();
+    if (!r) return nullptr;
+    r->tree = t;
+    const int64_t n = t->count();
+    if (n == 0) return r;
+    if (sync_device(t)) { delete r; return nullptr; }
+    std::vector<uint32_t> hits((size_t)n);
+    int64_t nh = 0;
+    if (pct_radius_indices_q64(t->cloud, q, range, hits.data(), n, &nh) != PCT_OK) { complain("kd_nearest_range"); delete r; return nullptr; }
+    // replay the reference walk's pruning and visit order over the device's hit list
+    struct Hit { int32_t id; std::vector<uint8_t> path; };
+    std::vector<Hit> kept;
+    kept.reserve((size_t)nh);
+    std::vector<uint8_t> path;
+    for (int64_t i = 0; i < nh; i++)
+        if (walk_path(t, (int32_t)hits[i], q, range, path)) kept.push_back(Hit{ (int32_t)hits[i], path });
+    // pre-order, nearer child before farther child: an ancestor's path is a proper prefix of its
+    // descendants' and sorts first; siblings sort by their first differing step
+    std::sort(kept.begin(), kept.end(), [](const Hit &a, const Hit &b) {
+        return std::lexicographical_compare(a.path.begin(), a.path.end(), b.path.begin(), b.path.end());
+    });
+    r->items.reserve(kept.size());
+    for (size_t i = kept.size(); i-- > 0;) r->items.push_back(kept[i].id);   // head insertion => reverse visit order
+    r->size = (int)r->items.size();
+    return r;
+}
+struct kdres *kd_nearest_rangef(struct kdtree *t, const float *q, float range)
+{
+    const double w[3] = { q[0], q[1], q[2] };
+    return kd_nearest_range(t, w, range);
+}
+struct kdres *kd_nearest_range3(struct kdtree *t, double x, double y, double z, double range)
+{
+    const double w[3] = { x, y, z };
+    return kd_nearest_range(t, w, range);
+}
+struct kdres *kd_nearest_range3f(struct kdtree *t, float x, float y, float z, float range)
+{
+    const double w[3] = { x, y, z };
+    return kd_nearest_range(t, w, range);
+}
+
+// kdtree.c:613-639
+void kd_res_free(struct kdres *r) { delete r; }
+int kd_res_size(struct kdres *r) { return r->size; }
+void kd_res_rewind(struct kdres *r) { r->cursor = 0; }
+int kd_res_end(struct kdres *r) { return r->cursor >= r->items.size(); }
+int kd_res_next(struct kdres *r)
+{
+    if (r->cursor < r->items.size()) r->cursor++;
+    return r->cursor < r->items.size();
+}
+
+// kdtree.c:641-664
+void *kd_res_item(struct kdres *r, double *pos)
+{
+    if (r->cursor >= r->items.size()) return nullptr;
+    const int32_t n = r->items[r->cursor];
+    if (pos) std::memcpy(pos, &r->tree->pos[3 * (size_t)n], 3 * sizeof(double));
+    return r->tree->data[n];
+}
+void *kd_res_itemf(struct kdres *r, float *pos)
+{
+    if (r->cursor >= r->items.size()) return nullptr;
+    const int32_t n = r->items[r->cursor];
+    if (pos) for (int i = 0; i < 3; i++) pos[i] = (float)r->tree->pos[3 * (size_t)n + i];
+    return r->tree->data[n];
+}
+// kdtree.c:666-684: tests the pointee, never returns the payload -- kept as is
+void *kd_res_item3(struct kdres *r, double *x, double *y, double *z)
+{
+    if (r->cursor < r->items.size()) {
+        const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
+        if (*x) *x = p[0];
+        if (*y) *y = p[1];
+        if (*z) *z = p[2];
+    }
+    return nullptr;
+}
+void *kd_res_item3f(struct kdres *r, float *x, float *y, float *z)
+{
+    if (r->cursor < r->items.size()) {
+        const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
+        if (*x) *x = (float)p[0];
+        if (*y) *y = (float)p[1];
+        if (*z) *z = (float)p[2];
+    }
+    return nullptr;
+}
+void *kd_res_item_data(struct kdres *r) { return kd_res_item(r, nullptr); }
+
+}  // extern "C"

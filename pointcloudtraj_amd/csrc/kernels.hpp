@@ -129,22 +129,269 @@ __global__ __launch_bounds__(256) void nn_stream_kernel(const float *__restrict_
     }
 }
 
-// one wave per query folds the per-block partials; adds the shard's index base
-__global__ __launch_bounds__(64) void nn_reduce_partials_kernel(const double *__restrict__ part_d2,
-                                                                const uint32_t *__restrict__ part_idx, int nparts,
-                                                                uint32_t index_base, uint32_t *__restrict__ out_idx,
-                                                                double *__restrict__ out_d2)
+// -------------------------------------------------------------------------------------
+// fp32 filter + exact fp64 recheck, LDS-staged (the default brute-force path for Q > 4).
+//
+// Measured on MI355X (profiles/r01_c): an fp64 vector op costs ~8 cycles per wave and a plain
+// fp32 op ~4; only the packed v_pk_{add,mul,fma}_f32 forms reach the fp32 peak (2 lanes-worth per
+// 4 cycles).  The all-fp64 kernel above needs 12 slow ops per (point, query) pair and tops out at
+// 1.8e12 pairs/s.  Exactness only matters for the few points that can win, so:
+//   1. nn_sample_bounds_kernel: packed-fp32 minimum over a 1/16 sample of the cloud per query.
+//      ANY upper bound of the true minimum is a valid threshold; the sample only makes it tight.
+//   2. nn_tile_filter_kernel: each block stages its contiguous chunk of the SoA cloud in LDS
+//      ONCE (HBM is read once per launch whatever Q is), then walks the query batch in tiles of
+//      QT wave-uniform queries.  Every pair is evaluated in packed fp32 on two points at a time
+//      (per 4 points and query: 6 pk_add, 2 pk_mul, 4 pk_fma, min3+min, one compare).  When the
+//      smallest of the four fp32 distances is <= thr = bound * (1 + 2^-19) + 2^-90 the group is
+//      re-evaluated in the exact fp64 arithmetic and competes by (d2, index).
+// Why nothing is lost: the fp32 value d32 of a pair differs from the exact d2 by < 4e-7 relative
+// (correctly rounded differences, three non-negative products, two sums: no cancellation) plus
+// underflow (< 2^-120 absolute).  The true winner w satisfies d2(w) <= d2(p) for the sample point
+// p that set the bound, so d32(w) <= d2(w)(1+e) <= d2(p)(1+e) <= d32(p)(1+e)/(1-e) < thr.  Hence w
+// and every exact tie of it always reach the fp64 path: results equal nn_stream_kernel's bit for bit.
+// -------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+constexpr int kSampleStride = 16;     // sample one 1024-point chunk out of every 16
+constexpr int kTileQ = 8;             // wave-uniform queries per tile (7 scalar registers each)
+constexpr int kSampleGroups = 4;      // sampled 256-group chunks per block of the bound kernel
+
+struct PointGroup { v2f x01, x23, y01, y23, z01, z23; };
+
+__device__ __forceinline__ PointGroup make_group(const float4 X, const float4 Y, const float4 Z)
+{
+    PointGroup g;
+    g.x01 = v2f{ X.x, X.y }; g.x23 = v2f{ X.z, X.w };
+    g.y01 = v2f{ Y.x, Y.y }; g.y23 = v2f{ Y.z, Y.w };
+    g.z01 = v2f{ Z.x, Z.y }; g.z23 = v2f{ Z.z, Z.w };
+    return g;
+}
+
+// smallest fp32 squared distance from the 4 points of g to (qx,qy,qz): 12 packed ops + min3 + min
+__device__ __forceinline__ float group_min_d32(const PointGroup &g, float qx, float qy, float qz)
+{
+    const v2f qx2 = v2f{ qx, qx }, qy2 = v2f{ qy, qy }, qz2 = v2f{ qz, qz };
+    const v2f dx01 = g.x01 - qx2, dx23 = g.x23 - qx2;
+    const v2f dy01 = g.y01 - qy2, dy23 = g.y23 - qy2;
+    const v2f dz01 = g.z01 - qz2, dz23 = g.z23 - qz2;
+    v2f d01 = dx01 * dx01, d23 = dx23 * dx23;
+    d01 = __builtin_elementwise_fma(dy01, dy01, d01);
+    d23 = __builtin_elementwise_fma(dy23, dy23, d23);
+    d01 = __builtin_elementwise_fma(dz01, dz01, d01);
+    d23 = __builtin_elementwise_fma(dz23, dz23, d23);
+    return fminf(fminf(d01.x, d01.y), fminf(d23.x, d23.y));
+}
+
+// Block-wide minimum of QT floats per thread through LDS (one transposed pass + a 32-lane
+// butterfly instead of 6 cross-lane steps per value).  s_red: QT*256 floats.  Result for query j
+// is returned by threads with (tid >> 5) == j, lane bit pattern (tid & 31) == 0.
+template <int QT>
+__device__ __forceinline__ float block_min_transposed(const float (&m)[QT], float *s_red)
+{
+    static_assert(QT <= 8, "one 32-lane group per query");
+#pragma unroll
+    for (int j = 0; j < QT; j++) s_red[j * 256 + threadIdx.x] = m[j];
+    __syncthreads();
+    const int j = threadIdx.x >> 5, l = threadIdx.x & 31;
+    float v = __builtin_huge_valf();
+    if (j < QT) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) v = fminf(v, s_red[j * 256 + l + 32 * i]);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+    __syncthreads();
+    return v;
+}
+
+// grid = sampled chunks / kSampleGroups; block b looks at kSampleGroups chunks of 256 groups, one
+// every `sample_stride` chunks (the per-tile block reduction is amortised over them).  One launch
+// covers the whole query batch: bound_part[q * nsblocks + b].
+__global__ __launch_bounds__(256) void nn_sample_bounds_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                               const float *__restrict__ z, uint32_t n, uint32_t sample_stride,
+                                                               const float *__restrict__ qf, int Q,
+                                                               float *__restrict__ bound_part, int nsblocks)
+{
+    __shared__ float s_red[kTileQ * 256];
+    const uint32_t ngroups = n >> 2;
+    const float big = __builtin_huge_valf();   // filler for slots past the end: its d32 is +inf and never lowers a bound
+    PointGroup pg[kSampleGroups];
+#pragma unroll
+    for (int c = 0; c < kSampleGroups; c++) {
+        const uint32_t g = (blockIdx.x * kSampleGroups + c) * sample_stride * 256u + threadIdx.x;
+        pg[c] = make_group(make_float4(big, big, big, big), make_float4(big, big, big, big), make_float4(big, big, big, big));
+        if (g < ngroups) pg[c] = make_group(reinterpret_cast<const float4 *>(x)[g], reinterpret_cast<const float4 *>(y)[g],
+                                            reinterpret_cast<const float4 *>(z)[g]);
+    }
+    for (int q0 = 0; q0 < Q; q0 += kTileQ) {
+        const int qcount = min(kTileQ, Q - q0);
+        float m[kTileQ];
+#pragma unroll
+        for (int j = 0; j < kTileQ; j++) {
+            const int qi = q0 + (j < qcount ? j : qcount - 1);
+            const float qx = qf[3 * qi], qy = qf[3 * qi + 1], qz = qf[3 * qi + 2];
+            float v = group_min_d32(pg[0], qx, qy, qz);
+#pragma unroll
+            for (int c = 1; c < kSampleGroups; c++) v = fminf(v, group_min_d32(pg[c], qx, qy, qz));
+            m[j] = v;
+        }
+        const float v = block_min_transposed<kTileQ>(m, s_red);
+        const int j = threadIdx.x >> 5;
+        if ((threadIdx.x & 31) == 0 && j < qcount) bound_part[(size_t)(q0 + j) * nsblocks + blockIdx.x] = v;
+    }
+}
+
+// one block per query: fold the sample partials into the fp32 bound (bit pattern; FLT_MAX when
+// the sample was empty, which makes the filter recheck everything)
+__global__ __launch_bounds__(256) void bound_reduce_kernel(const float *__restrict__ bound_part, int nsblocks,
+                                                           uint32_t *__restrict__ bound_bits)
+{
+    const float *p = bound_part + (size_t)blockIdx.x * nsblocks;
+    float v = 3.402823466e+38f;
+    for (int i = threadIdx.x; i < nsblocks; i += 256) v = fminf(v, p[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, kWave));
+    __shared__ float s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) bound_bits[blockIdx.x] = __float_as_uint(fminf(fminf(s[0], s[1]), fminf(s[2], s[3])));
+}
+
+// grid = chunks of `chunk_groups` 4-point groups; dynamic LDS = 3 * chunk_groups float4.
+// Queries [qbase, qbase+Q) of the batch; partials at part[(q - qbase) * nparts + block].
+__global__ __launch_bounds__(256) void nn_tile_filter_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, uint32_t n, uint32_t chunk_groups,
+                                                             const float *__restrict__ qf, const double *__restrict__ q64,
+                                                             const uint32_t *__restrict__ bound_bits, int qbase, int Q,
+                                                             double *__restrict__ part_d2, uint32_t *__restrict__ part_idx,
+                                                             int nparts)
+{
+    extern __shared__ float4 s_pts[];                 // [3][chunk_groups]
+    __shared__ double s_d[4][kTileQ];
+    __shared__ uint32_t s_i[4][kTileQ];
+    const uint32_t ngroups = n >> 2;
+    const uint32_t g0 = blockIdx.x * chunk_groups;
+    const uint32_t ng = min(chunk_groups, ngroups > g0 ? ngroups - g0 : 0u);
+    float4 *sx = s_pts, *sy = s_pts + chunk_groups, *sz = s_pts + 2 * chunk_groups;
+    for (uint32_t i = threadIdx.x; i < ng; i += 256) {
+        sx[i] = reinterpret_cast<const float4 *>(x)[g0 + i];
+        sy[i] = reinterpret_cast<const float4 *>(y)[g0 + i];
+        sz[i] = reinterpret_cast<const float4 *>(z)[g0 + i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool tail_owner = (blockIdx.x == gridDim.x - 1) && threadIdx.x < (n & 3u);   // n % 4 leftover points
+
+    for (int q0 = 0; q0 < Q; q0 += kTileQ) {
+        const int qcount = min(kTileQ, Q - q0);
+        float qx[kTileQ], qy[kTileQ], qz[kTileQ], thr[kTileQ];
+#pragma unroll
+        for (int j = 0; j < kTileQ; j++) {
+            const int qi = qbase + q0 + (j < qcount ? j : qcount - 1);
+            qx[j] = qf[3 * qi]; qy[j] = qf[3 * qi + 1]; qz[j] = qf[3 * qi + 2];
+            thr[j] = __uint_as_float(bound_bits[qi]) * (1.0f + 0x1p-19f) + 0x1p-90f;   // FLT_MAX bound -> +inf: recheck everything
+        }
+        double bd[kTileQ];
+        uint32_t bi[kTileQ];
+#pragma unroll
+        for (int j = 0; j < kTileQ; j++) { bd[j] = __builtin_huge_val(); bi[j] = kNoIndex; }
+
+        for (uint32_t i = threadIdx.x; i < ng; i += 256) {
+            const float4 X = sx[i], Y = sy[i], Z = sz[i];
+            const PointGroup pg = make_group(X, Y, Z);
+            // the compare results stay in scalar registers (one s_or per query, no per-lane flags)
+            unsigned long long hit = 0ull;
+#pragma unroll
+            for (int j = 0; j < kTileQ; j++) hit |= __builtin_amdgcn_ballot_w64(group_min_d32(pg, qx[j], qy[j], qz[j]) <= thr[j]);
+            // wave-uniform branch: taken only when some lane holds a possible winner for some query
+            if (hit != 0ull) {
+                if ((hit >> lane) & 1ull) {
+                    const float xs[4] = { X.x, X.y, X.z, X.w }, ys[4] = { Y.x, Y.y, Y.z, Y.w }, zs[4] = { Z.x, Z.y, Z.z, Z.w };
+#pragma unroll
+                    for (int j = 0; j < kTileQ; j++) {
+                        const int qi = qbase + q0 + (j < qcount ? j : qcount - 1);
+                        const double Qx = q64[3 * qi], Qy = q64[3 * qi + 1], Qz = q64[3 * qi + 2];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const double d2 = dist2((double)xs[k], (double)ys[k], (double)zs[k], Qx, Qy, Qz);
+                            if (d2 < bd[j]) { bd[j] = d2; bi[j] = 4u * (g0 + i) + (uint32_t)k; }   // ids grow within a thread
+                        }
+                    }
+                }
+            }
+        }
+        if (tail_owner) {
+            const uint32_t id = 4u * ngroups + threadIdx.x;
+            const double px = (double)x[id], py = (double)y[id], pz = (double)z[id];
+#pragma unroll
+            for (int j = 0; j < kTileQ; j++) {
+                const int qi = qbase + q0 + (j < qcount ? j : qcount - 1);
+                const double d2 = dist2(px, py, pz, q64[3 * qi], q64[3 * qi + 1], q64[3 * qi + 2]);
+                if (better(d2, id, bd[j], bi[j])) { bd[j] = d2; bi[j] = id; }
+            }
+        }
+        // block winner per query; almost every lane holds (+inf, none), so skip the exchange then
+#pragma unroll
+        for (int j = 0; j < kTileQ; j++) {
+            double d = bd[j];
+            uint32_t ix = bi[j];
+            if (__builtin_amdgcn_ballot_w64(ix != kNoIndex) != 0ull) wave_argmin(d, ix);
+            if (lane == 0) { s_d[wave][j] = d; s_i[wave][j] = ix; }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < qcount) {
+            const int j = threadIdx.x;
+            double d = s_d[0][j];
+            uint32_t ix = s_i[0][j];
+#pragma unroll
+            for (int w = 1; w < 4; w++)
+                if (better(s_d[w][j], s_i[w][j], d, ix)) { d = s_d[w][j]; ix = s_i[w][j]; }
+            part_d2[(size_t)(q0 + j) * nparts + blockIdx.x] = d;
+            part_idx[(size_t)(q0 + j) * nparts + blockIdx.x] = ix;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// one 256-thread block per query folds the per-block partials (loads issued back to back,
+// compared afterwards); adds the shard's index base
+__global__ __launch_bounds__(256) void nn_reduce_partials_kernel(const double *__restrict__ part_d2,
+                                                                 const uint32_t *__restrict__ part_idx, int nparts,
+                                                                 uint32_t index_base, uint32_t *__restrict__ out_idx,
+                                                                 double *__restrict__ out_d2)
 {
     const int q = blockIdx.x;
+    const double *pd = part_d2 + (size_t)q * nparts;
+    const uint32_t *pi = part_idx + (size_t)q * nparts;
     double d = __builtin_huge_val();
     uint32_t i = kNoIndex;
-    for (int p = threadIdx.x; p < nparts; p += 64) {
-        const double pd = part_d2[(size_t)q * nparts + p];
-        const uint32_t pi = part_idx[(size_t)q * nparts + p];
-        if (better(pd, pi, d, i)) { d = pd; i = pi; }
+    for (int base = 0; base < nparts; base += 1024) {
+        double ld[4];
+        uint32_t li[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p = base + k * 256 + (int)threadIdx.x;
+            ld[k] = p < nparts ? pd[p] : __builtin_huge_val();
+            li[k] = p < nparts ? pi[p] : kNoIndex;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (better(ld[k], li[k], d, i)) { d = ld[k]; i = li[k]; }
     }
     wave_argmin(d, i);
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; w++)
+            if (better(s_d[w], s_i[w], d, i)) { d = s_d[w]; i = s_i[w]; }
         out_idx[q] = (i == kNoIndex) ? kNoIndex : i + index_base;
         out_d2[q] = d;
     }
@@ -433,6 +680,39 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restri
     }
 }
 
+// Query binning for the cell-pruned kernels: a counting sort of the batch by coarse cell
+// ((cx,cy,cz) >> shift, x fastest) so that neighbouring lanes walk neighbouring cells and
+// share cache lines.  Random 1M-query batches ran 2.5x faster pre-sorted (profiles/r01_b).
+struct BinDesc { int shift, bx, by, bz; uint32_t nbins; };
+
+__device__ __forceinline__ uint32_t query_bin(const GridDesc &G, const BinDesc &B, float qx, float qy, float qz)
+{
+    const int cx = cell_coord(qx, G.ox, G.inv_h, G.gx) >> B.shift;
+    const int cy = cell_coord(qy, G.oy, G.inv_h, G.gy) >> B.shift;
+    const int cz = cell_coord(qz, G.oz, G.inv_h, G.gz) >> B.shift;
+    return ((uint32_t)cz * (uint32_t)B.by + (uint32_t)cy) * (uint32_t)B.bx + (uint32_t)cx;
+}
+
+__global__ __launch_bounds__(256) void query_bin_count_kernel(GridDesc G, BinDesc B, const float *__restrict__ q, uint32_t Q,
+                                                              uint32_t *__restrict__ bin_count, uint32_t *__restrict__ qbin)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q) return;
+    const uint32_t b = query_bin(G, B, q[3 * t], q[3 * t + 1], q[3 * t + 2]);
+    qbin[t] = b;
+    atomicAdd(&bin_count[b], 1u);
+}
+
+__global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *__restrict__ qbin, uint32_t Q,
+                                                                const uint32_t *__restrict__ bin_start,
+                                                                uint32_t *__restrict__ bin_fill, uint32_t *__restrict__ perm)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q) return;
+    const uint32_t b = qbin[t];
+    perm[bin_start[b] + atomicAdd(&bin_fill[b], 1u)] = t;
+}
+
 // =====================================================================================
 // 4. Cell-pruned kernels: one lane per query walks an expanding cube of cells.
 //    Termination is exact: a point outside the scanned cube of cells is at least
@@ -460,12 +740,14 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                       const uint32_t *__restrict__ cell_start,
                                                       const float *__restrict__ q, uint32_t Q, uint32_t index_base,
+                                                      const uint32_t *__restrict__ perm,
                                                       uint32_t *__restrict__ out_idx, double *__restrict__ out_d2,
                                                       WorkCounters *__restrict__ work)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t npts = 0, nruns = 0;
-    if (t < Q) {
+    if (slot < Q) {
+        const uint32_t t = perm ? perm[slot] : slot;     // binned order in, original order out
         const float qxf = q[3 * t], qyf = q[3 * t + 1], qzf = q[3 * t + 2];
         const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
         const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
@@ -522,18 +804,19 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                          const uint32_t *__restrict__ cell_start,
                                                          const float *__restrict__ q, const float *__restrict__ rad,
-                                                         uint32_t Q, uint32_t *__restrict__ count,
-                                                         WorkCounters *__restrict__ work)
+                                                         uint32_t Q, const uint32_t *__restrict__ perm,
+                                                         uint32_t *__restrict__ count, WorkCounters *__restrict__ work)
 {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t npts = 0, nruns = 0;
-    if (t < Q) {
+    if (slot < Q) {
+        const uint32_t t = perm ? perm[slot] : slot;
         const float qxf = q[3 * t], qyf = q[3 * t + 1], qzf = q[3 * t + 2], rf = rad[t];
         const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
         const double r2 = (double)rf * (double)rf;
         uint32_t c = 0;
-        if (rf >= 0.0f) {
-            const float pad = rf + 0.01f * (1.0f / G.inv_h);
+        {
+            const float pad = fabsf(rf) + 0.01f * (1.0f / G.inv_h);   // r enters only squared (kdtree.c:273)
             int x0 = cell_coord(qxf - pad, G.ox, G.inv_h, G.gx), x1 = cell_coord(qxf + pad, G.ox, G.inv_h, G.gx);
             int y0 = cell_coord(qyf - pad, G.oy, G.inv_h, G.gy), y1 = cell_coord(qyf + pad, G.oy, G.inv_h, G.gy);
             int z0 = cell_coord(qzf - pad, G.oz, G.inv_h, G.gz), z1 = cell_coord(qzf + pad, G.oz, G.inv_h, G.gz);

@@ -13,7 +13,7 @@ import numpy as np
 from . import build as _build
 
 NO_INDEX = 0xFFFFFFFF
-ALGO_AUTO, ALGO_STREAM, ALGO_GRID = 0, 1, 2
+ALGO_AUTO, ALGO_STREAM, ALGO_GRID, ALGO_STREAM_EXACT = 0, 1, 2, 3
 
 _lib = None
 
@@ -135,8 +135,8 @@ class Cloud:
         _chk(lib().pct_cloud_create(int(capacity), C.byref(self._h)))
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().pct_cloud_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.pct_cloud_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Kernel timing probe (GPU box): sweeps the tuning knobs and prints one line per configuration.
+Not part of the product or of bench.py; used to choose defaults recorded in DESIGN.md."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401  (first: one HIP runtime per process)
+from pointcloudtraj_amd import engine as E, synth  # noqa: E402
+
+N = int(os.environ.get("PROBE_N", 10_000_000))
+what = sys.argv[1] if len(sys.argv) > 1 else "all"
+E.init(0)
+pts = synth.uniform_points(3, N, 0, 100)
+c = E.Cloud(N)
+c.set_input(pts)
+qh = synth.uniform_points(5, 1 << 20, 0, 100)
+q = torch.from_numpy(qh).cuda()
+Qmax = len(qh)
+c.reserve_queries(Qmax)
+idx = torch.empty(Qmax, dtype=torch.int32, device="cuda")
+d2 = torch.empty(Qmax, dtype=torch.float64, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(Q, algo, reps=10):
+    for _ in range(2):
+        c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, algo)
+    ms = []
+    for _ in range(reps):
+        c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, algo)
+        ms.append(c.last_kernel_ms())
+    torch.cuda.synchronize()
+    return float(np.median(ms)), float(np.min(ms))
+
+
+if what in ("all", "stream"):
+    for name, algo, tile in (("exact ", E.ALGO_STREAM_EXACT, 8), ("filter", E.ALGO_STREAM, 16)):
+        for blocks in (1024, 2048):
+            os.environ["PCT_STREAM_BLOCKS"] = str(blocks)
+            for Q in (1, 2, 4, 8, 16, 64, 200, 4096):
+                med, mn = timeit(Q, algo, reps=5 if Q > 100 else 10)
+                passes = (Q + tile - 1) // tile
+                gbs = 12 * N * passes / (med * 1e-3) / 1e9
+                print(f"stream {name} blocks={blocks:5d} Q={Q:4d} median={med*1e3:9.1f}us min={mn*1e3:9.1f}us  {gbs:7.0f} GB/s ({gbs/80:.1f}% of 8TB/s)  pairs/s={Q*N/(med*1e-3):.3e}", flush=True)
+    os.environ.pop("PCT_STREAM_BLOCKS", None)
+
+if what in ("all", "grid"):
+    for ppc, shift in ((0.5, 1), (0.5, 2), (1.0, 1), (1.0, 2), (2.0, 0), (2.0, 1), (2.0, 2), (4.0, 1)):
+        os.environ["PCT_GRID_PPC"] = str(ppc)
+        os.environ["PCT_BIN_SHIFT"] = str(shift)
+        t0 = time.perf_counter()
+        c.build_grid()
+        E.sync()
+        tb = time.perf_counter() - t0
+        for Q in (4096, 1 << 16, 1 << 20):
+            med, mn = timeit(Q, E.ALGO_GRID)
+            print(f"grid ppc={ppc:4.1f} shift={shift} dims={c.grid_info()['dims']} build={tb*1e3:6.2f}ms Q={Q:8d} median={med*1e3:9.1f}us  {Q/(med*1e-3):.3e} q/s", flush=True)
+        c.set_work_counters(True)
+        c.nn_device(q.data_ptr(), 1 << 20, idx.data_ptr(), d2.data_ptr(), s, E.ALGO_GRID)
+        torch.cuda.synchronize()
+        print("    work (points, runs) per query:", [w / (1 << 20) for w in c.last_work()], flush=True)
+        c.set_work_counters(False)
+    # spatially coherent queries (sorted by grid cell) -- how much does locality buy?
+    os.environ["PCT_GRID_PPC"] = "2.0"
+    c.build_grid()
+    gi = c.grid_info()
+    h = gi["cell_size"]
+    cell = np.floor(qh / h).astype(np.int64)
+    key = (cell[:, 2] * gi["dims"][1] + cell[:, 1]) * gi["dims"][0] + cell[:, 0]
+    qs = torch.from_numpy(qh[np.argsort(key, kind="stable")]).cuda()
+    q_save = q
+    q = qs
+    med, mn = timeit(1 << 20, E.ALGO_GRID)
+    print(f"grid ppc=2.0 SORTED queries Q=1M median={med*1e3:9.1f}us  {(1<<20)/(med*1e-3):.3e} q/s", flush=True)
+    q = q_save

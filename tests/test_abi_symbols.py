@@ -39,3 +39,28 @@ def test_engine_fails_loudly_without_gpu(built):
     assert ei.value.code == 1 and "no host fallback" in str(ei.value)
     with pytest.raises(E.EngineError):
         E.Cloud(16)
+
+
+def test_kdtree_exports_every_reference_function(built):
+    names = declared("kdtree/kdtree.h", "kd_")
+    assert len(names) == 26
+    import ctypes as C2
+    from pointcloudtraj_amd import engine as E
+    E._preload_hip_runtime()
+    C2.CDLL(built.ENGINE_SO, mode=C2.RTLD_GLOBAL)
+    L = C2.CDLL(built.KDTREE_SO)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    want = ["kd_create", "kd_free", "kd_clear", "kd_data_destructor", "kd_insert", "kd_insertf", "kd_insert3", "kd_insert3f",
+            "kd_nearest", "kd_nearestf", "kd_nearest3", "kd_nearest3f", "kd_nearest_range", "kd_nearest_rangef",
+            "kd_nearest_range3", "kd_nearest_range3f", "kd_res_free", "kd_res_size", "kd_res_rewind", "kd_res_end",
+            "kd_res_next", "kd_res_item", "kd_res_itemf", "kd_res_item3", "kd_res_item3f", "kd_res_item_data"]
+    assert sorted(want) == names
+
+
+def test_kdtree_create_fails_loudly_without_gpu(built, capfd):
+    from pointcloudtraj_amd import engine as E, kdtree as K
+    if E.device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert K.lib().kd_create(3) is None
+    assert "no host fallback" in capfd.readouterr().err

@@ -40,13 +40,17 @@ def make_cloud(E, pts, grid=False, cell=0.0):
     return c
 
 
-@pytest.mark.parametrize("algo", ["stream", "grid"])
+def algo_id(E, algo):
+    return {"stream": E.ALGO_STREAM, "stream_exact": E.ALGO_STREAM_EXACT, "grid": E.ALGO_GRID}[algo]
+
+
+@pytest.mark.parametrize("algo", ["stream", "stream_exact", "grid"])
 @pytest.mark.parametrize("name", NN_FIXTURES)
 def test_nn_golden(E, name, algo):
     g = load_golden(name)
     pts = fixture_points(g)
     c = make_cloud(E, pts, grid=(algo == "grid"))
-    idx, d2 = c.nn(g["queries"], E.ALGO_GRID if algo == "grid" else E.ALGO_STREAM)
+    idx, d2 = c.nn(g["queries"], algo_id(E, algo))
     assert np.array_equal(d2, g["ref_d2"]), "squared distances must be bit-identical to kdtree.c"
     assert np.array_equal(idx.astype(np.int64), g["lowest_idx"].astype(np.int64))
     untied = g["tie"] == 0
@@ -152,9 +156,11 @@ def test_stream_vs_grid_vs_oracle_seeded(E, oracle):
         bi, bd = oracle.brute_nearest(pts, q)
         c = make_cloud(E, pts)
         i1, d1 = c.nn(q, E.ALGO_STREAM)
+        i3, d3 = c.nn(q, E.ALGO_STREAM_EXACT)
         c.build_grid()
         i2, d2 = c.nn(q, E.ALGO_GRID)
         assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+        assert np.array_equal(d3, bd) and np.array_equal(i3.astype(np.int64), bi.astype(np.int64))
         assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64))
         r = (np.float32(0.3) + synth.uniform01_f32(65, len(q)) * np.float32(6.0)).astype(np.float32)
         bc = oracle.brute_count(pts, q, r)
@@ -171,12 +177,51 @@ def test_ragged_sizes(E, oracle, n):
         q = synth.uniform_points(80 + nq, nq, -6, 6)
         bi, bd = oracle.brute_nearest(pts, q)
         c = make_cloud(E, pts)
-        i1, d1 = c.nn(q, E.ALGO_STREAM)
-        assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+        for a in (E.ALGO_STREAM, E.ALGO_STREAM_EXACT):
+            i1, d1 = c.nn(q, a)
+            assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
         c.build_grid()
         i2, d2 = c.nn(q, E.ALGO_GRID)
         assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64))
         c.close()
+
+
+def test_filter_adversarial_near_ties(E, oracle):
+    """The fp32 filter must never drop the fp64 winner: clouds built so that MANY points sit within a
+    few fp32 ulps of the minimum distance (shells of almost-equal radius around the query, far from
+    the origin so fp32 rounding of the differences is coarse), plus exact ties and coincident points."""
+    rng = np.random.default_rng(5)
+    ctr = np.float32([812.25, -431.5, 97.125])
+    dirs = rng.normal(size=(30000, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    rad = 3.0 + rng.uniform(-2e-6, 2e-6, size=(30000, 1))          # shell thickness ~ a few fp32 ulps of d2
+    shell = (ctr.astype(np.float64) + dirs * rad).astype(np.float32)
+    far = (ctr + synth.uniform_points(7, 60000, 5, 400)).astype(np.float32)
+    pts = np.concatenate([far[:30000], shell, far[30000:], shell[:100]])   # duplicates of shell points: exact ties
+    q = np.concatenate([ctr[None], ctr[None] + np.float32([[1e-3, 0, 0], [0, 2e-3, 0]]), shell[:5], far[:24]])
+    bi, bd = oracle.brute_nearest(pts, q)
+    c = make_cloud(E, pts)
+    for a in (E.ALGO_STREAM, E.ALGO_STREAM_EXACT):
+        i1, d1 = c.nn(q, a)
+        assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    c.build_grid()
+    i2, d2 = c.nn(q, E.ALGO_GRID)
+    assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64))
+    c.close()
+
+
+def test_large_batch_query_binning(E, oracle):
+    """Batches >= 16384 queries are counting-sorted by coarse cell on the device before the
+    cell-pruned kernels run; results must come back in the caller's order and unchanged."""
+    pts = synth.uniform_points(66, 60000, 0, 40)
+    q = np.concatenate([synth.uniform_points(67, 39000, -3, 43), pts[:1000]])
+    bi, bd = oracle.brute_nearest(pts, q)
+    c = make_cloud(E, pts, grid=True)
+    i2, d2 = c.nn(q, E.ALGO_GRID)
+    assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64))
+    r = (np.float32(0.2) + synth.uniform01_f32(68, len(q)) * np.float32(3.0)).astype(np.float32)
+    assert np.array_equal(c.radius_count(q, r, E.ALGO_GRID).astype(np.int64), oracle.brute_count(pts, q, r))
+    c.close()
 
 
 def test_aos16_and_ring_append(E, oracle):
