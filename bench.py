@@ -34,6 +34,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command
+    (scripts/prof_bench.sh -> profiles/*_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes).
+    None when no summary is committed (PMC counters cannot be collected inside the timed run)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.items():
+            if kernel in k and "derived_hbm_traffic_bytes_per_launch" in v:
+                best = v["derived_hbm_traffic_bytes_per_launch"]
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,10 +142,13 @@ def main():
     ms_per_step = 1e3 * elapsed / a.steps
 
     # kernel time from HIP events on the launch stream, averaged over extra untimed passes
+    batch_ms = []
     for _ in range(max(3, min(a.steps, 10))):
         sc.nn_local(q, algo)
         kern_ms.append(sc.cloud.last_kernel_ms())
+        batch_ms.append(sc.cloud.last_batch_ms())
     k_ms = float(np.mean(kern_ms))
+    b_ms = float(np.mean(batch_ms))
     # algorithmic work of one launch (separate instrumented pass)
     sc.cloud.set_work_counters(True)
     sc.nn_local(q, algo)
@@ -168,28 +188,54 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": measured_traffic("nn_grid_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel"),
             "kernel": "nn_grid_kernel" if algo == E.ALGO_GRID else "nn_stream_kernel<8>",
-            "kernel_ms": k_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
+            "kernel_ms": k_ms, "batch_kernels_ms": b_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
             "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
         },
     }
 
-    # streaming kernel at its HBM-bound operating point (Q = 8 per pass), same cloud
     if a.stream_probe and world == 1:
-        q8 = q[:8].contiguous()
+        cs = torch.cuda.current_stream().cuda_stream
+
+        def timed(fn, reps):
+            for _ in range(2):
+                fn()
+            ms = []
+            for _ in range(reps):
+                fn()
+                ms.append(sc.cloud.last_kernel_ms())
+            return float(np.median(ms))
+
+        # (a) streaming kernel at its HBM-bound operating points: the SoA cloud is read once per pass
+        probes = []
+        for qn in (1, 2, 4):
+            ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 20)
+            sb = 12 * len(local_pts) + 24 * qn
+            probes.append({"queries": qn, "kernel_ms": ms, "algorithmic_bytes": sb, "achieved_GBs": sb / (ms * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        out["stream_probe"] = {"kernel": "nn_stream_kernel<QT> + nn_reduce_partials_kernel (all-fp64, one pass over the SoA cloud)",
+                               "points": probes}
+        # (b) brute force at config C2's batch size: LDS-tiled packed-fp32 filter + exact fp64 recheck
+        qn = 4096
+        ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 5)
+        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + nn_tile_filter_kernel + nn_reduce_partials_kernel",
+                                    "queries": qn, "kernel_ms": ms, "queries_per_s": qn / (ms * 1e-3),
+                                    "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
+                                    "flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}
+        # (c) corridor side (config C3): sphere inflation of 200 seeds against the 10M-point cloud through the
+        # host-buffer entry point (PCIe and launch latency included) -- ms per pass
+        seeds = synth.uniform_points(4, 200, 10.0, 90.0).astype(np.float64)
+        prm = E.inflate_params((50.0, 50.0, 50.0), 1.0e9, 0.25, 1.5)
         for _ in range(3):
-            sc.cloud.nn_device(q8.data_ptr(), 8, sc._idx32.data_ptr(), sc._d2.data_ptr(), torch.cuda.current_stream().cuda_stream, E.ALGO_STREAM)
-        ms = []
+            sc.cloud.inflate(prm, seeds)
+        ts = []
         for _ in range(20):
-            sc.cloud.nn_device(q8.data_ptr(), 8, sc._idx32.data_ptr(), sc._d2.data_ptr(), torch.cuda.current_stream().cuda_stream, E.ALGO_STREAM)
-            ms.append(sc.cloud.last_kernel_ms())
-        sms = float(np.median(ms))
-        sb = 12 * len(local_pts) + 24 * 8
-        out["stream_probe"] = {"kernel": "nn_stream_kernel<8> + reduce", "queries": 8, "kernel_ms": sms,
-                               "algorithmic_bytes": sb, "achieved_GBs": sb / (sms * 1e-3) / 1e9,
-                               "frac_of_hbm_peak": sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                               "pair_evals_per_s": 8 * len(local_pts) / (sms * 1e-3)}
+            t1 = time.perf_counter()
+            sc.cloud.inflate(prm, seeds)
+            ts.append(1e3 * (time.perf_counter() - t1))
+        out["corridor_probe"] = {"what": "pct_inflate_batch, 200 seeds (seed 4), search_margin 0.25, max_radius 1.5, host buffers",
+                                 "ms_per_pass_median": float(np.median(ts)), "ms_per_pass_p99": float(np.percentile(ts, 99))}
 
     if a.cpu_queries > 0 and world == 1:
         ncpu = a.cpu_points or a.points

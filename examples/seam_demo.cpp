@@ -48,7 +48,11 @@ int main()
         double best = INFINITY; uint32_t bi = 0;
         for (uint32_t k = 0; k < cloud.size(); k++) { double s = host_d2(cloud[k], q); if (s < best) { best = s; bi = k; } }
         double want = std::sqrt(best) - 0.25; if (want > 1.5) want = 1.5;
-        if (best != d2[i] || bi != idx[i] || want != rad[i]) { bad++; std::printf("inflate mismatch at %d\n", i); }
+        // corridor_finder.cpp:115-116: farther than sample_range + max_radius from the start -> max_radius - margin, no NN
+        const double sx = pts[3 * i] - start[0], sy = pts[3 * i + 1] - start[1], sz = pts[3 * i + 2] - start[2];
+        if (std::sqrt(sx * sx + sy * sy + sz * sz) > 30.0 + 1.5) {
+            if (rad[i] != 1.25 || idx[i] != PCT_NO_INDEX || !std::isinf(d2[i])) { bad++; std::printf("early-out mismatch at %d\n", i); }
+        } else if (best != d2[i] || bi != idx[i] || want != rad[i]) { bad++; std::printf("inflate mismatch at %d\n", i); }
         if (i < 8 && map.radiusSearch(&pts[3 * i]) != rad[i]) { bad++; std::printf("single radiusSearch mismatch at %d\n", i); }
         if (i < 8 && map.checkTrajPtCol(&pts[3 * i]) != (rad[i] < 0)) bad++;
     }

@@ -146,9 +146,12 @@ int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out);
 int pct_plan_run(pct_plan *p, const float *q, uint32_t *idx, double *d2);
 int pct_plan_destroy(pct_plan *p);
 
-/* ---- measurement hooks (bench.py): time of the last query batch's kernels on the stream
- * they ran on, from HIP events recorded around them ---------------------------------------- */
+/* ---- measurement hooks (bench.py): HIP events recorded on the stream the kernels ran on.
+ * pct_last_kernel_ms: the last batch's DOMINANT kernel alone (nn_grid_kernel, nn_tile_filter_kernel
+ * or the nn_stream_kernel passes) -- the same quantity rocprofv3 --kernel-trace averages;
+ * pct_last_batch_ms: every kernel of the batch (binning, bounds, reduction included). ---------- */
 int pct_last_kernel_ms(pct_cloud *c, float *ms);
+int pct_last_batch_ms(pct_cloud *c, float *ms);
 /* algorithmic work of the last batch: points examined (sum over queries), cells examined */
 int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
 int pct_set_work_counters(pct_cloud *c, int enabled);

@@ -105,8 +105,9 @@ struct pct_cloud {
     long long *d_first_hit = nullptr;
     size_t coef_cap = 0, seg_cap = 0;
     // measurement
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool ev_valid = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the whole batch (all kernels of one query call)
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;    // around the batch's dominant kernel only
+    bool ev_valid = false, dom_valid = false;
     WorkCounters *d_work = nullptr;
     bool count_work = false;
     bool host_work = false;        // last batch's work is known on the host (streaming kernel)
@@ -216,11 +217,26 @@ void end_timing(pct_cloud *c, hipStream_t s)
     if (hipEventRecord(c->ev1, s) != hipSuccess) c->ev_valid = false;
 }
 
+// events around the dominant kernel of the batch (what rocprofv3's per-kernel average also measures)
+void dom_begin(pct_cloud *c, hipStream_t s)
+{
+    c->dom_valid = false;
+    if (c->capturing) return;
+    if (hipEventRecord(c->ev2, s) == hipSuccess) c->dom_valid = true;
+}
+
+void dom_end(pct_cloud *c, hipStream_t s)
+{
+    if (c->capturing || !c->dom_valid) return;
+    if (hipEventRecord(c->ev3, s) != hipSuccess) c->dom_valid = false;
+}
+
 // streaming NN over the fp64 queries already in c->d_q64
 int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
 {
     const int blocks = stream_blocks(c->count);
     begin_timing(c, s);
+    dom_begin(c, s);
     for (int64_t q0 = 0; q0 < Q;) {
         const int qt = pick_tile(Q - q0);
         const int qcount = (int)std::min<int64_t>(qt, Q - q0);
@@ -232,6 +248,7 @@ int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStr
         }
         q0 += qcount;
     }
+    dom_end(c, s);
     nn_reduce_partials_kernel<<<(int)Q, 256, 0, s>>>(c->d_part_d2, c->d_part_idx, blocks, (uint32_t)c->index_base, d_idx, d_d2);
     end_timing(c, s);
     HIPCHK(hipGetLastError());
@@ -297,8 +314,10 @@ int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_i
     const int64_t qb_max = std::max<int64_t>(kTileQ, part_cap / nblocks / kTileQ * kTileQ);
     for (int64_t qbase = 0; qbase < Q; qbase += qb_max) {
         const int qb = (int)std::min<int64_t>(qb_max, Q - qbase);
+        if (qbase == 0) dom_begin(c, s);
         nn_tile_filter_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, c->d_q64,
                                                                                        c->d_bound, (int)qbase, qb, c->d_part_d2, c->d_part_idx, nblocks);
+        if (qbase == 0) dom_end(c, s);
         nn_reduce_partials_kernel<<<qb, 256, 0, s>>>(c->d_part_d2, c->d_part_idx, nblocks, (uint32_t)c->index_base, d_idx + qbase, d_d2 + qbase);
     }
     end_timing(c, s);
@@ -325,12 +344,14 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
         PCTCHK(bin_queries(c, d_q, Q, s, &perm));
+        dom_begin(c, s);
         if (c->count_work)
             nn_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
                                                                    (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
         else
             nn_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
                                                                     (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
+        dom_end(c, s);
         end_timing(c, s);
         HIPCHK(hipGetLastError());
         return PCT_OK;
@@ -454,7 +475,8 @@ int pct_cloud_create(int64_t capacity, pct_cloud **out)
         pct_cloud_destroy(c);
         return s;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess ||
+        hipEventCreate(&c->ev3) != hipSuccess) {
         pct_cloud_destroy(c);
         return fail(PCT_ERR_HIP, "hipEventCreate failed");
     }
@@ -476,6 +498,8 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_work);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
     delete c;
     return PCT_OK;
 }
@@ -935,6 +959,15 @@ int pct_plan_destroy(pct_plan *p)
 
 // ---- measurement -------------------------------------------------------------------------
 int pct_last_kernel_ms(pct_cloud *c, float *ms)
+{
+    if (!c || !ms) return fail(PCT_ERR_INVALID, "bad arguments");
+    if (!c->dom_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
+    HIPCHK(hipEventSynchronize(c->ev3));
+    HIPCHK(hipEventElapsedTime(ms, c->ev2, c->ev3));
+    return PCT_OK;
+}
+
+int pct_last_batch_ms(pct_cloud *c, float *ms)
 {
     if (!c || !ms) return fail(PCT_ERR_INVALID, "bad arguments");
     if (!c->ev_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");

@@ -721,6 +721,18 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
 // =====================================================================================
 struct WorkCounters { unsigned long long points, cells; };
 
+// XCD-aware block order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over
+// the 8 XCDs, each with a private 4 MiB L2.  With the batch binned in cell order, giving XCD k
+// the k-th contiguous eighth of the blocks keeps the three cell planes a stretch of queries
+// needs inside ONE L2 instead of spreading every plane over all eight.  Bijective for any grid
+// size; placement is a speed matter only.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nblocks)
+{
+    const uint32_t xcd = b & 7u, k = b >> 3;
+    const uint32_t q = nblocks >> 3, r = nblocks & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void scan_run(const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
                                          uint32_t lin0, uint32_t lin1, double qx, double qy, double qz, double &bd,
@@ -744,7 +756,7 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
                                                       uint32_t *__restrict__ out_idx, double *__restrict__ out_d2,
                                                       WorkCounters *__restrict__ work)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = (perm ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
     uint32_t npts = 0, nruns = 0;
     if (slot < Q) {
         const uint32_t t = perm ? perm[slot] : slot;     // binned order in, original order out
@@ -807,7 +819,7 @@ __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float
                                                          uint32_t Q, const uint32_t *__restrict__ perm,
                                                          uint32_t *__restrict__ count, WorkCounters *__restrict__ work)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t slot = (perm ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x) * blockDim.x + threadIdx.x;
     uint32_t npts = 0, nruns = 0;
     if (slot < Q) {
         const uint32_t t = perm ? perm[slot] : slot;

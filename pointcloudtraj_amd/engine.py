@@ -91,6 +91,7 @@ def lib():
         L.pct_plan_run.argtypes = [vp, f32p, u32p, f64p]
         L.pct_plan_destroy.argtypes = [vp]
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_set_work_counters.argtypes = [vp, i32]
         _lib = L
@@ -258,6 +259,11 @@ class Cloud:
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         _chk(lib().pct_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_batch_ms(self) -> float:
+        ms = C.c_float()
+        _chk(lib().pct_last_batch_ms(self._h, C.byref(ms)))
         return ms.value
 
     def set_work_counters(self, on: bool):
