@@ -102,7 +102,8 @@ def main():
     rank, local, world = D.init_process_group_from_env()
     if world != a.gpus and world > 1:
         a.gpus = world
-    dev = local if world > 1 else 0
+    # one GPU per rank; PCT_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks on one card
+    dev = (local % max(torch.cuda.device_count(), 1)) if world > 1 else 0
     n_total = a.points * world
     side = 100.0 * (world ** (1.0 / 3.0))      # constant density as the cloud grows
     Q = a.queries
@@ -136,7 +137,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=sc.device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=sc.device if tdist.get_backend() == "nccl" else "cpu")
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / a.steps

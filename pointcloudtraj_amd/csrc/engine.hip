@@ -91,6 +91,10 @@ struct pct_cloud {
     uint32_t *bin_start = nullptr, *bin_fill = nullptr, *bin_tiles = nullptr;   // query binning (sized at grid build)
     size_t bins_cap = 0;
     uint32_t *d_qbin = nullptr, *d_perm = nullptr;                              // sized by reserve_queries
+    float4 *d_qsorted = nullptr;
+    float4 *d_sorttmp = nullptr;                                                // {x,y,z,id} records of the two-level sort
+    uint32_t *d_sortkey = nullptr;                                              // their keys
+    uint32_t *d_sort1 = nullptr;                                                // total1 | start1(+1) | cursor1
     // query workspaces
     int64_t qcap = 0;
     float *d_q = nullptr, *d_r = nullptr;
@@ -265,6 +269,22 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
     if (const char *e = std::getenv("PCT_SORT_MIN_Q")) min_q = std::atoll(e);
     if (Q < min_q) return PCT_OK;
     const BinDesc &B = c->B;
+    static const bool lds_sort = [] { const char *e = std::getenv("PCT_LDS_SORT"); return e ? std::atoi(e) != 0 : true; }();
+    if (lds_sort) {
+        // two-level counting sort on LDS histograms (kernels.hpp)
+        int key_shift = 0;
+        while ((((uint64_t)B.nbins - 1) >> key_shift) >= (1ull << 20)) key_shift++;
+        uint32_t *total1 = c->d_sort1, *start1 = c->d_sort1 + kSortBuckets, *cursor1 = c->d_sort1 + 2 * kSortBuckets + 4;
+        const int nb = ceil_div(Q, kSortPerBlock);
+        HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));
+        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, d_q, (uint32_t)Q, c->d_qbin, total1);
+        qsort_scan1_kernel<<<1, 256, 0, s>>>(total1, start1, cursor1);
+        qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, cursor1, c->d_sortkey, c->d_sorttmp);
+        qsort_fine_kernel<<<kSortBuckets, 256, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, c->d_perm, c->d_qsorted);
+        HIPCHK(hipGetLastError());
+        *perm_out = c->d_perm;
+        return PCT_OK;
+    }
     const uint32_t ntiles = (B.nbins + kScanTile - 1) / kScanTile;
     HIPCHK(hipMemsetAsync(c->bin_fill, 0, sizeof(uint32_t) * B.nbins, s));
     query_bin_count_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->G, B, d_q, (uint32_t)Q, c->bin_fill, c->d_qbin);
@@ -272,7 +292,7 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
     scan_tile_sums_kernel<<<1, 256, 0, s>>>(c->bin_tiles, ntiles);
     scan_add_kernel<<<ceil_div(B.nbins, 256), 256, 0, s>>>(c->bin_start, B.nbins, c->bin_tiles, (uint32_t)Q);
     HIPCHK(hipMemsetAsync(c->bin_fill, 0, sizeof(uint32_t) * B.nbins, s));
-    query_bin_scatter_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->d_qbin, (uint32_t)Q, c->bin_start, c->bin_fill, c->d_perm);
+    query_bin_scatter_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->d_qbin, (uint32_t)Q, c->bin_start, c->bin_fill, d_q, c->d_perm, c->d_qsorted);
     HIPCHK(hipGetLastError());
     *perm_out = c->d_perm;
     return PCT_OK;
@@ -340,12 +360,21 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
     if (algo == PCT_ALGO_GRID) {
         if (!c->has_grid) return fail(PCT_ERR_INVALID, "PCT_ALGO_GRID without a grid (call pct_cloud_build_grid)");
         c->host_work = false;
-        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
+        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters) * kWorkSlots, s));
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
         PCTCHK(bin_queries(c, d_q, Q, s, &perm));
+        static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
         dom_begin(c, s);
-        if (c->count_work)
+        if (coop) {   // 8 lanes per query (default)
+            const int blocks = ceil_div(Q, 256 / kCoop);
+            if (c->count_work)
+                nn_grid_coop_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
+                                                                  perm ? c->d_qsorted : nullptr, d_idx, d_d2, c->d_work);
+            else
+                nn_grid_coop_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
+                                                                   perm ? c->d_qsorted : nullptr, d_idx, d_d2, c->d_work);
+        } else if (c->count_work)
             nn_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
                                                                    (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
         else
@@ -375,7 +404,7 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
     if (algo == PCT_ALGO_GRID) {
         if (!c->has_grid) return fail(PCT_ERR_INVALID, "PCT_ALGO_GRID without a grid");
         c->host_work = false;
-        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters), s));
+        if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters) * kWorkSlots, s));
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
         PCTCHK(bin_queries(c, d_q, Q, s, &perm));
@@ -471,7 +500,7 @@ int pct_cloud_create(int64_t capacity, pct_cloud **out)
     c->cap4 = (capacity + 3) & ~3ll;
     int s;
     if ((s = dev_alloc(&c->x, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->y, (size_t)c->cap4 + 4)) ||
-        (s = dev_alloc(&c->z, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->d_work, 1))) {
+        (s = dev_alloc(&c->z, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->d_work, kWorkSlots))) {
         pct_cloud_destroy(c);
         return s;
     }
@@ -490,7 +519,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (g_stream) (void)hipStreamSynchronize(g_stream);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
-    dev_free(c->d_qbin); dev_free(c->d_perm);
+    dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx);
@@ -569,7 +598,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     const int64_t q = std::max<int64_t>(Q, 256);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_qbin); dev_free(c->d_perm);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
     c->qcap = 0;
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
     PCTCHK(dev_alloc(&c->d_r, q));
@@ -584,6 +613,10 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_bound, q));
     PCTCHK(dev_alloc(&c->d_qbin, q));
     PCTCHK(dev_alloc(&c->d_perm, q));
+    PCTCHK(dev_alloc(&c->d_qsorted, q));
+    PCTCHK(dev_alloc(&c->d_sorttmp, q));
+    PCTCHK(dev_alloc(&c->d_sortkey, q));
+    if (!c->d_sort1) PCTCHK(dev_alloc(&c->d_sort1, 3 * kSortBuckets + 8));
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)q * kMaxParts));
     PCTCHK(dev_alloc(&c->d_part_idx, (size_t)q * kMaxParts));
     c->qcap = q;
@@ -708,7 +741,10 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     B.bx = ((G.gx - 1) >> B.shift) + 1;
     B.by = ((G.gy - 1) >> B.shift) + 1;
     B.bz = ((G.gz - 1) >> B.shift) + 1;
-    B.nbins = (uint32_t)B.bx * (uint32_t)B.by * (uint32_t)B.bz;
+    B.strip = 16;
+    if (const char *es = std::getenv("PCT_BIN_STRIP")) B.strip = std::max(1, std::atoi(es));
+    B.strip = std::min(B.strip, B.by);
+    B.nbins = (uint32_t)B.bx * (uint32_t)(((B.by + B.strip - 1) / B.strip) * B.strip) * (uint32_t)B.bz;
     if ((size_t)B.nbins + 1 > c->bins_cap) {
         dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
         c->bins_cap = 0;
@@ -998,8 +1034,10 @@ int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanne
     if (c->host_work) {
         w.points = c->host_points;
     } else {
+        WorkCounters slots[kWorkSlots];
         HIPCHK(hipStreamSynchronize(g_stream));
-        HIPCHK(hipMemcpy(&w, c->d_work, sizeof w, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(slots, c->d_work, sizeof slots, hipMemcpyDeviceToHost));
+        for (const WorkCounters &k : slots) { w.points += k.points; w.cells += k.cells; }
     }
     if (points_scanned) *points_scanned = w.points;
     if (cells_scanned) *cells_scanned = w.cells;

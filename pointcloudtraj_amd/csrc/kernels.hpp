@@ -683,14 +683,19 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restri
 // Query binning for the cell-pruned kernels: a counting sort of the batch by coarse cell
 // ((cx,cy,cz) >> shift, x fastest) so that neighbouring lanes walk neighbouring cells and
 // share cache lines.  Random 1M-query batches ran 2.5x faster pre-sorted (profiles/r01_b).
-struct BinDesc { int shift, bx, by, bz; uint32_t nbins; };
+// Bin order = (y-strip, z, y inside the strip, x): walking the batch in this order sweeps a strip
+// of `strip` bin rows through all z before moving to the next strip, so the planes a stretch of
+// queries re-uses (z-1, z, z+1) are a strip wide, not a whole plane wide, and stay inside one
+// XCD's 4 MiB L2 (a full-plane sweep re-fetched every plane ~3x: profiles/r01_d).
+struct BinDesc { int shift, bx, by, bz, strip; uint32_t nbins; };
 
 __device__ __forceinline__ uint32_t query_bin(const GridDesc &G, const BinDesc &B, float qx, float qy, float qz)
 {
     const int cx = cell_coord(qx, G.ox, G.inv_h, G.gx) >> B.shift;
     const int cy = cell_coord(qy, G.oy, G.inv_h, G.gy) >> B.shift;
     const int cz = cell_coord(qz, G.oz, G.inv_h, G.gz) >> B.shift;
-    return ((uint32_t)cz * (uint32_t)B.by + (uint32_t)cy) * (uint32_t)B.bx + (uint32_t)cx;
+    const uint32_t s = (uint32_t)cy / (uint32_t)B.strip, yin = (uint32_t)cy % (uint32_t)B.strip;
+    return ((s * (uint32_t)B.bz + (uint32_t)cz) * (uint32_t)B.strip + yin) * (uint32_t)B.bx + (uint32_t)cx;
 }
 
 __global__ __launch_bounds__(256) void query_bin_count_kernel(GridDesc G, BinDesc B, const float *__restrict__ q, uint32_t Q,
@@ -703,14 +708,148 @@ __global__ __launch_bounds__(256) void query_bin_count_kernel(GridDesc G, BinDes
     atomicAdd(&bin_count[b], 1u);
 }
 
+// perm[pos] = original query id; qsorted[pos] = {qx, qy, qz, bitcast(id)} so the NN kernel gets a
+// query and its output slot with ONE 16-byte load instead of a perm -> q dependent pair
 __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *__restrict__ qbin, uint32_t Q,
                                                                 const uint32_t *__restrict__ bin_start,
-                                                                uint32_t *__restrict__ bin_fill, uint32_t *__restrict__ perm)
+                                                                uint32_t *__restrict__ bin_fill, const float *__restrict__ q,
+                                                                uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Q) return;
     const uint32_t b = qbin[t];
-    perm[bin_start[b] + atomicAdd(&bin_fill[b], 1u)] = t;
+    const uint32_t pos = bin_start[b] + atomicAdd(&bin_fill[b], 1u);
+    perm[pos] = t;
+    qsorted[pos] = make_float4(q[3 * t], q[3 * t + 1], q[3 * t + 2], __uint_as_float(t));
+}
+
+// Two-level counting sort of the batch on LDS histograms (replaces the global-atomic version
+// above for large batches: 2 M scattered device-scope atomics ran at ~20 G/s = 100 us per 1 M
+// queries, profiles/r01_d).  key = bin >> key_shift (< 2^20); level 1 = key >> 10 (<= 1024
+// buckets), level 2 = key & 1023 inside a bucket.  Global atomics are one per (block, non-empty
+// bucket); everything else is LDS atomics and coalesced traffic.
+constexpr int kSortBuckets = 1024;
+constexpr int kSortPerBlock = 8192;      // queries per block in the level-1 kernels
+
+__global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, const float *__restrict__ q,
+                                                          uint32_t Q, uint32_t *__restrict__ keys, uint32_t *__restrict__ total1)
+{
+    __shared__ uint32_t h[kSortBuckets];
+    for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortPerBlock;
+    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+        const uint32_t t = base + i;
+        if (t < Q) {
+            const uint32_t key = query_bin(G, B, q[3 * t], q[3 * t + 1], q[3 * t + 2]) >> key_shift;
+            keys[t] = key;
+            atomicAdd(&h[key >> 10], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSortBuckets; i += 1024)
+        if (h[i]) atomicAdd(&total1[i], h[i]);
+}
+
+// single block: start1 = exclusive scan of total1 (kSortBuckets entries, +1 terminator); cursor1 = copy
+__global__ __launch_bounds__(256) void qsort_scan1_kernel(const uint32_t *__restrict__ total1, uint32_t *__restrict__ start1,
+                                                          uint32_t *__restrict__ cursor1)
+{
+    __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = total1[threadIdx.x * 4 + k];
+    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, kWave);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - tsum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        start1[threadIdx.x * 4 + k] = run;
+        cursor1[threadIdx.x * 4 + k] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == 255) start1[kSortBuckets] = run;
+}
+
+// level 1 scatter: the query record {x, y, z, bitcast(id)} travels with its key, so the fine pass
+// never gathers from the (randomly ordered) input again
+__global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__restrict__ keys, const float *__restrict__ q,
+                                                              uint32_t Q, uint32_t *__restrict__ cursor1,
+                                                              uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec)
+{
+    __shared__ uint32_t h[kSortBuckets];
+    __shared__ uint32_t basepos[kSortBuckets];
+    for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortPerBlock;
+    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+        const uint32_t t = base + i;
+        if (t < Q) atomicAdd(&h[keys[t] >> 10], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSortBuckets; i += 1024) {
+        basepos[i] = h[i] ? atomicAdd(&cursor1[i], h[i]) : 0u;     // reserve this block's slice of bucket i
+        h[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+        const uint32_t t = base + i;
+        if (t < Q) {
+            const uint32_t key = keys[t];
+            const uint32_t pos = basepos[key >> 10] + atomicAdd(&h[key >> 10], 1u);
+            tmp_key[pos] = key;
+            tmp_rec[pos] = make_float4(q[3 * t], q[3 * t + 1], q[3 * t + 2], __uint_as_float(t));
+        }
+    }
+}
+
+// one block per level-1 bucket: counting sort by the low 10 key bits, then emit perm / qsorted
+__global__ __launch_bounds__(256) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
+                                                         const uint32_t *__restrict__ start1,
+                                                         uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
+{
+    __shared__ uint32_t h[kSortBuckets];
+    __shared__ uint32_t s_wave[4];
+    const uint32_t s = start1[blockIdx.x], e = start1[blockIdx.x + 1];
+    if (s == e) return;
+    for (int i = threadIdx.x; i < kSortBuckets; i += 256) h[i] = 0;
+    __syncthreads();
+    for (uint32_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&h[tmp_key[i] & 1023u], 1u);
+    __syncthreads();
+    // exclusive scan of h[1024] in place: 4 entries per thread
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = h[threadIdx.x * 4 + k];
+    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    uint32_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, kWave);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - tsum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { h[threadIdx.x * 4 + k] = run; run += v[k]; }
+    __syncthreads();
+    for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
+        const float4 rec = tmp_rec[i];
+        const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & 1023u], 1u);
+        perm[pos] = __float_as_uint(rec.w);
+        qsorted[pos] = rec;
+    }
 }
 
 // =====================================================================================
@@ -720,6 +859,7 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
 //    assignment rounding), so the search stops once best_d2 <= bound^2.
 // =====================================================================================
 struct WorkCounters { unsigned long long points, cells; };
+constexpr int kWorkSlots = 64;    // instrumented kernels spread their two counters over 64 slots (same-address atomics serialise)
 
 // XCD-aware block order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over
 // the 8 XCDs, each with a private 4 MiB L2.  With the batch binned in cell order, giving XCD k
@@ -733,6 +873,48 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nb
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Points [s, e) of the cell-sorted array against one query.  Four independent 16-byte loads are
+// issued before the first compare (the tail repeats the last point: a repeated (d2, index) never
+// changes the winner), so a short run costs one memory round trip instead of one per point.
+__device__ __forceinline__ void scan_points(const float4 *__restrict__ pts, uint32_t s, uint32_t e, double qx, double qy,
+                                            double qz, double &bd, uint32_t &bi)
+{
+    for (uint32_t p = s; p < e; p += 4) {
+        const uint32_t last = e - 1;
+        const float4 P0 = pts[p], P1 = pts[min(p + 1, last)], P2 = pts[min(p + 2, last)], P3 = pts[min(p + 3, last)];
+        const float4 P[4] = { P0, P1, P2, P3 };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double d2 = dist2((double)P[k].x, (double)P[k].y, (double)P[k].z, qx, qy, qz);
+            const uint32_t id = __float_as_uint(P[k].w);
+            if (better(d2, id, bd, bi)) { bd = d2; bi = id; }
+        }
+    }
+}
+
+// fp32 screening of points [s, e): tracks the smallest and second-smallest fp32 distance and the
+// array position of the smallest.  Tail slots of the 4-wide load group count as +inf (a repeated
+// point would fake a tie).
+__device__ __forceinline__ void screen_points(const float4 *__restrict__ pts, uint32_t s, uint32_t e, float qx, float qy,
+                                              float qz, float &m1, float &m2, uint32_t &p1)
+{
+    for (uint32_t p = s; p < e; p += 4) {
+        const uint32_t last = e - 1;
+        const float4 P0 = pts[p], P1 = pts[min(p + 1, last)], P2 = pts[min(p + 2, last)], P3 = pts[min(p + 3, last)];
+        const float4 P[4] = { P0, P1, P2, P3 };
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float dx = P[k].x - qx, dy = P[k].y - qy, dz = P[k].z - qz;
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            if (k > 0) d = (p + k <= last) ? d : __builtin_huge_valf();
+            const bool lt = d < m1;
+            m2 = lt ? m1 : fminf(m2, d);
+            p1 = lt ? p + (uint32_t)k : p1;
+            m1 = fminf(m1, d);
+        }
+    }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void scan_run(const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
                                          uint32_t lin0, uint32_t lin1, double qx, double qy, double qz, double &bd,
@@ -740,12 +922,7 @@ __device__ __forceinline__ void scan_run(const float4 *__restrict__ pts, const u
 {
     const uint32_t s = cell_start[lin0], e = cell_start[lin1 + 1];
     if (COUNT) { npts += e - s; nruns += 1; }
-    for (uint32_t p = s; p < e; p++) {
-        const float4 P = pts[p];
-        const double d2 = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
-        const uint32_t id = __float_as_uint(P.w);
-        if (better(d2, id, bd, bi)) { bd = d2; bi = id; }
-    }
+    scan_points(pts, s, e, qx, qy, qz, bd, bi);
 }
 
 template <bool COUNT>
@@ -772,6 +949,69 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
             const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
             const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
             const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
+            if (r == 1) {
+                // first cube (3x3x3 cells = 9 contiguous x-runs; almost every query ends here): the 18
+                // cell_start reads are independent, so issue them all before touching any point
+                uint32_t rs[9], re[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int zz = cz + k / 3 - 1, yy = cy + k % 3 - 1;
+                    const bool ok = zz >= 0 && zz < G.gz && yy >= 0 && yy < G.gy;    // rows outside the grid hold nothing
+                    const uint32_t row = ok ? cell_lin(G, 0, yy, zz) : 0u;
+                    const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
+                    rs[k] = a;
+                    re[k] = ok ? b : a;
+                    if (COUNT) { npts += re[k] - rs[k]; nruns += ok ? 1u : 0u; }
+                }
+                // fp32 screening first: fp64 costs ~3x per point, and 53 points are looked at per query.
+                // If the runner-up is farther than the fp32 error band the fp32 argmin IS the exact
+                // winner (every other point p has d2(p) >= d32(p)/(1+e) > d2(best); e < 4e-7, band 2^-19)
+                // and one exact evaluation finishes the query; otherwise (near-ties, duplicates) the
+                // runs are re-scanned in the exact arithmetic so the (d2, index) order decides.
+                float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+                uint32_t p1 = 0;
+                // one z-plane (3 rows) at a time: the first 4 points of each row are requested together
+                // (12 independent 16-byte loads in flight), rows longer than 4 continue 4 at a time.
+                // The kernel is bound by dependent memory round trips, not by arithmetic (profiles/r01_d).
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    float4 P[3][4];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const uint32_t a = rs[3 * g + j], b = re[3 * g + j];
+                        const uint32_t last = b > a ? b - 1 : 0u;      // empty row: read slot 0, masked below
+#pragma unroll
+                        for (int k = 0; k < 4; k++) P[j][k] = pts[min(a + (uint32_t)k, last)];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        const uint32_t a = rs[3 * g + j], b = re[3 * g + j];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float dx = P[j][k].x - qxf, dy = P[j][k].y - qyf, dz = P[j][k].z - qzf;
+                            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                            d = (a + (uint32_t)k < b) ? d : __builtin_huge_valf();
+                            const bool lt = d < m1;
+                            m2 = lt ? m1 : fminf(m2, d);
+                            p1 = lt ? a + (uint32_t)k : p1;
+                            m1 = fminf(m1, d);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; j++)
+                        if (re[3 * g + j] > rs[3 * g + j] + 4u) screen_points(pts, rs[3 * g + j] + 4u, re[3 * g + j], qxf, qyf, qzf, m1, m2, p1);
+                }
+                if (m1 < __builtin_huge_valf()) {
+                    if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {
+                        const float4 P = pts[p1];
+                        bd = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
+                        bi = __float_as_uint(P.w);
+                    } else {
+#pragma unroll 1
+                        for (int k = 0; k < 9; k++) scan_points(pts, rs[k], re[k], qx, qy, qz, bd, bi);
+                    }
+                }
+            } else
             for (int zz = z0; zz <= z1; zz++) {
                 const bool zface = (zz == cz - r) || (zz == cz + r);
                 for (int yy = y0; yy <= y1; yy++) {
@@ -806,7 +1046,214 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
             a += (unsigned long long)__shfl_xor((long long)a, off, kWave);
             b += (unsigned long long)__shfl_xor((long long)b, off, kWave);
         }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&work->points, a); atomicAdd(&work->cells, b); }
+        if ((threadIdx.x & 63) == 0) { WorkCounters *w = work + (blockIdx.x & (kWorkSlots - 1)); atomicAdd(&w->points, a); atomicAdd(&w->cells, b); }
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Cooperative form of the cell-pruned NN: EIGHT lanes per query (8 queries per wave).
+//
+// The lane-per-query kernel above is bound by the vector L1's address path, not by arithmetic or
+// DRAM (profiles/r01_d: ~150 L1 accesses per query, texture-address unit busy 65 % of the kernel):
+// a lane reading the 6 points of a run one after the other issues 6 separate 16-byte accesses to
+// the SAME 128-byte line.  Here the 8 lanes of a group read 8 consecutive points of a run with one
+// coalesced 128-byte access, the 9 rows' cell_start entries are fetched by 9 different lanes at
+// once, and the three rows of a z-plane are requested before any is consumed.
+// Arithmetic and results are identical to nn_grid_kernel (same screening rule, same exact fp64
+// winner by (d2, index), same termination bound).
+// -------------------------------------------------------------------------------------
+constexpr int kCoop = 8;
+
+__device__ __forceinline__ void coop_argmin8(double &d, uint32_t &i)
+{
+#pragma unroll
+    for (int off = 1; off < kCoop; off <<= 1) {
+        const double od = __shfl_xor(d, off, kWave);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)i, off, kWave);
+        if (better(od, oi, d, i)) { d = od; i = oi; }
+    }
+}
+
+// exact scan of [s, e) shared by the 8 lanes of a group (lane `sub` takes s+sub, s+sub+8, ...)
+__device__ __forceinline__ void coop_scan_exact(const float4 *__restrict__ pts, uint32_t s, uint32_t e, uint32_t sub, double qx,
+                                                double qy, double qz, double &bd, uint32_t &bi)
+{
+    for (uint32_t p = s + sub; p < e; p += kCoop) {
+        const float4 P = pts[p];
+        const double d2 = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
+        const uint32_t id = __float_as_uint(P.w);
+        if (better(d2, id, bd, bi)) { bd = d2; bi = id; }
+    }
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
+                                                           const uint32_t *__restrict__ cell_start,
+                                                           const float *__restrict__ q, uint32_t Q, uint32_t index_base,
+                                                           const float4 *__restrict__ qsorted,
+                                                           uint32_t *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                           WorkCounters *__restrict__ work)
+{
+    const uint32_t sub = threadIdx.x & (kCoop - 1);
+    const uint32_t bslot = qsorted ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t slot = bslot * (256 / kCoop) + (threadIdx.x / kCoop);
+    uint32_t npts = 0, nruns = 0;
+    if (slot < Q) {                                   // uniform within a group of 8 lanes
+        uint32_t t = slot;
+        float qxf, qyf, qzf;
+        if (qsorted) {                                // binned batch: query and output slot in one record
+            const float4 R = qsorted[slot];
+            qxf = R.x; qyf = R.y; qzf = R.z; t = __float_as_uint(R.w);
+        } else {
+            qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
+        }
+        const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+        const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+        const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+        const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+        double bd = __builtin_huge_val();
+        uint32_t bi = kNoIndex;
+        const double slack = G.hd * (1.0 / 256.0);
+        {   // ---- first cube: 3x3x3 cells = 9 x-runs ----
+            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
+            // lane `sub` fetches row `sub`'s bounds, lane 0 also row 8
+            uint32_t my_s = 0, my_e = 0, s8 = 0, e8 = 0;
+            {
+                const int zz = cz + (int)sub / 3 - 1, yy = cy + (int)sub % 3 - 1;
+                const bool ok = zz >= 0 && zz < G.gz && yy >= 0 && yy < G.gy;
+                const uint32_t row = ok ? cell_lin(G, 0, yy, zz) : 0u;
+                const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
+                my_s = a;
+                my_e = ok ? b : a;
+                const int z8 = cz + 1, y8 = cy + 1;
+                const bool ok8 = z8 < G.gz && y8 < G.gy;
+                const uint32_t row8 = ok8 ? cell_lin(G, 0, y8, z8) : 0u;
+                const uint32_t a8 = cell_start[row8 + x0], b8 = cell_start[row8 + x1 + 1];   // same address in all 8 lanes: one access
+                s8 = a8;
+                e8 = ok8 ? b8 : a8;
+                if (COUNT && sub == 0) {
+                    npts += e8 - s8; nruns += ok8 ? 1u : 0u;
+                }
+                if (COUNT) {
+                    // every lane adds its own row; summed over the wave at the end
+                    npts += my_e - my_s; nruns += ok ? 1u : 0u;
+                }
+            }
+            uint32_t rs[9], re[9];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
+            rs[8] = s8; re[8] = e8;
+
+            float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+            uint32_t p1 = 0;
+            // all nine rows are requested before any is consumed (the kernel is bound by dependent
+            // memory round trips: one for the bounds, one for the points)
+            float4 P[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const uint32_t a = rs[k], b = re[k];
+                const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
+                P[k] = pts[min(a + sub, last)];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const uint32_t a = rs[k], b = re[k];
+                const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
+                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                d = (a + sub < b) ? d : __builtin_huge_valf();
+                const bool lt = d < m1;
+                m2 = lt ? m1 : fminf(m2, d);
+                p1 = lt ? a + sub : p1;
+                m1 = fminf(m1, d);
+            }
+#pragma unroll 1
+            for (int k = 0; k < 9; k++) {                                // rows longer than 8 points
+                const uint32_t b = re[k];
+                for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
+                    const float4 Pp = pts[p];
+                    const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
+                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    const bool lt = d < m1;
+                    m2 = lt ? m1 : fminf(m2, d);
+                    p1 = lt ? p : p1;
+                    m1 = fminf(m1, d);
+                }
+            }
+            // fold (smallest, runner-up, position) over the 8 lanes
+#pragma unroll
+            for (int off = 1; off < kCoop; off <<= 1) {
+                const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
+                const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
+                const bool lt = o1 < m1;
+                m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
+                p1 = lt ? op : p1;
+                m1 = fminf(m1, o1);
+            }
+            if (m1 < __builtin_huge_valf()) {
+                if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {            // unique within the fp32 error band: it is the exact winner
+                    const float4 P = pts[p1];
+                    bd = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
+                    bi = __float_as_uint(P.w);
+                } else {                                                  // near-ties / duplicates: exact (d2, index) order decides
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) coop_scan_exact(pts, rs[k], re[k], sub, qx, qy, qz, bd, bi);
+                    coop_argmin8(bd, bi);
+                }
+            }
+        }
+        for (int r = 1;; r++) {
+            if (r > 1) {   // ---- shell r (rare): rows walked in the same order by the whole group ----
+                const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
+                const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
+                const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
+                for (int zz = z0; zz <= z1; zz++) {
+                    const bool zface = (zz == cz - r) || (zz == cz + r);
+                    for (int yy = y0; yy <= y1; yy++) {
+                        const uint32_t row = cell_lin(G, 0, yy, zz);
+                        if (zface || yy == cy - r || yy == cy + r) {
+                            const uint32_t s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                        } else {
+                            if (cx - r >= 0) {
+                                const uint32_t s = cell_start[row + cx - r], e = cell_start[row + cx - r + 1];
+                                if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                                coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                            }
+                            if (cx + r <= G.gx - 1) {
+                                const uint32_t s = cell_start[row + cx + r], e = cell_start[row + cx + r + 1];
+                                if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                                coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                            }
+                        }
+                    }
+                }
+                coop_argmin8(bd, bi);
+            }
+            double bound = __builtin_huge_val();
+            if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
+            if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
+            if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
+            if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
+            if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
+            if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
+            if (bound == __builtin_huge_val()) break;
+            bound -= slack;
+            if (bound > 0.0 && bd <= bound * bound) break;
+        }
+        if (sub == 0) {
+            out_idx[t] = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+            out_d2[t] = bd;
+        }
+    }
+    if (COUNT) {
+        unsigned long long a = npts, b = nruns;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += (unsigned long long)__shfl_xor((long long)a, off, kWave);
+            b += (unsigned long long)__shfl_xor((long long)b, off, kWave);
+        }
+        if ((threadIdx.x & 63) == 0) { WorkCounters *w = work + (blockIdx.x & (kWorkSlots - 1)); atomicAdd(&w->points, a); atomicAdd(&w->cells, b); }
     }
 }
 
@@ -855,7 +1302,7 @@ __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float
             a += (unsigned long long)__shfl_xor((long long)a, off, kWave);
             b += (unsigned long long)__shfl_xor((long long)b, off, kWave);
         }
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&work->points, a); atomicAdd(&work->cells, b); }
+        if ((threadIdx.x & 63) == 0) { WorkCounters *w = work + (blockIdx.x & (kWorkSlots - 1)); atomicAdd(&w->points, a); atomicAdd(&w->cells, b); }
     }
 }
 

@@ -30,9 +30,24 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return (rank * n_total) // world, ((rank + 1) * n_total) // world
 
 
+def _staging(t: torch.Tensor, group=None) -> torch.Tensor:
+    """gloo rehearsals of the multi-rank path on a GPU box stage through host memory (gloo's device
+    support is not guaranteed on ROCm); with RCCL the tensors stay in HBM."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return t.cpu()
+    return t
+
+
 def merge_nearest(d2: torch.Tensor, idx: torch.Tensor, group=None) -> tuple[torch.Tensor, torch.Tensor]:
     """Exchange step for 1-NN.  d2: fp64 [Q] per-shard minima (+inf for an empty shard);
     idx: int64 [Q] GLOBAL indices (anything where d2 is +inf).  Returns the global (d2, idx)."""
+    dev = d2.device
+    d2, idx = _staging(d2, group), _staging(idx, group)
+    best, cand = _merge_nearest(d2, idx, group)
+    return best.to(dev), cand.to(dev)
+
+
+def _merge_nearest(d2, idx, group):
     best = d2.clone()
     dist.all_reduce(best, op=dist.ReduceOp.MIN, group=group)
     cand = torch.where((d2 == best) & torch.isfinite(d2), idx, torch.full_like(idx, _I64_MAX))
@@ -41,9 +56,10 @@ def merge_nearest(d2: torch.Tensor, idx: torch.Tensor, group=None) -> tuple[torc
 
 
 def merge_counts(count: torch.Tensor, group=None) -> torch.Tensor:
-    total = count.clone()
+    dev = count.device
+    total = _staging(count, group).clone()
     dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-    return total
+    return total.to(dev)
 
 
 def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, int]:
@@ -55,7 +71,7 @@ def init_process_group_from_env(backend: str | None = None) -> tuple[int, int, i
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PCT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))

@@ -26,13 +26,13 @@ d2 = torch.empty(Qmax, dtype=torch.float64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 
 
-def timeit(Q, algo, reps=10):
+def timeit(Q, algo, reps=10, batch=True):
     for _ in range(2):
         c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, algo)
     ms = []
     for _ in range(reps):
         c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, algo)
-        ms.append(c.last_kernel_ms())
+        ms.append(c.last_batch_ms() if batch else c.last_kernel_ms())
     torch.cuda.synchronize()
     return float(np.median(ms)), float(np.min(ms))
 
@@ -58,7 +58,8 @@ if what in ("all", "grid"):
         tb = time.perf_counter() - t0
         for Q in (4096, 1 << 16, 1 << 20):
             med, mn = timeit(Q, E.ALGO_GRID)
-            print(f"grid ppc={ppc:4.1f} shift={shift} dims={c.grid_info()['dims']} build={tb*1e3:6.2f}ms Q={Q:8d} median={med*1e3:9.1f}us  {Q/(med*1e-3):.3e} q/s", flush=True)
+            kmed, _ = timeit(Q, E.ALGO_GRID, batch=False)
+            print(f"[kernel only {kmed*1e3:7.1f}us] grid ppc={ppc:4.1f} shift={shift} dims={c.grid_info()['dims']} build={tb*1e3:6.2f}ms Q={Q:8d} median={med*1e3:9.1f}us  {Q/(med*1e-3):.3e} q/s", flush=True)
         c.set_work_counters(True)
         c.nn_device(q.data_ptr(), 1 << 20, idx.data_ptr(), d2.data_ptr(), s, E.ALGO_GRID)
         torch.cuda.synchronize()

@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT && mkdir -p $OUT
-ARGS="--steps 10 --warmup 2 --cpu-queries 0"
+ARGS="--steps 10 --warmup 2 --cpu-queries 0 --stream-probe 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.log 2>&1
 echo trace_rc=$?
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > $OUT/bench_pmc_fetch.log 2>&1
