@@ -6,7 +6,8 @@
 A "step" is one pass of the hot path over one batch of synthetic queries: the batched 1-NN
 (pct_nn_batch_dev, include/pct_engine.h) of Q queries against the cloud resident in HBM.
 Workload at N=1 (config C3-throughput of SURVEY.md section 8(d)): 10,000,000 uniform points in
-[0,100)^3 (seed 3), Q = 1,048,576 uniform queries (seed 5), cell-pruned kernel.
+[0,100)^3 (seed 3), Q = 1,048,576 uniform queries (seed 5), cell-pruned kernel (device-side query
+binning + nn_grid_coop_kernel).
 At N>1 (weak scaling): the cloud grows to N x 10M points at constant
 density, rank r owns the contiguous index range [r*10M, (r+1)*10M) in its own HBM, the query
 batch is replicated, every rank runs the same kernel on its shard and ONE exchange step
@@ -46,7 +47,7 @@ def measured_traffic(kernel: str):
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if kernel in k and "derived_hbm_traffic_bytes_per_launch" in v:
+            if kernel in k and "<true>" not in k and "derived_hbm_traffic_bytes_per_launch" in v:   # <true> = instrumented twin
                 best = v["derived_hbm_traffic_bytes_per_launch"]
     return best
 
@@ -189,8 +190,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic("nn_grid_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel"),
-            "kernel": "nn_grid_kernel" if algo == E.ALGO_GRID else "nn_stream_kernel<8>",
+            "traffic": measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel"),
+            "kernel": "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel",
             "kernel_ms": k_ms, "batch_kernels_ms": b_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
             "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
         },

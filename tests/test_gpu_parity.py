@@ -325,3 +325,63 @@ def test_full_size_properties_c2(E, oracle):
     r_miss = np.where(r_miss.astype(np.float64) ** 2 < d1[:256], r_miss, np.nextafter(r_miss, np.float32(0)))
     assert np.all(c.radius_count(q[:256], r_miss, E.ALGO_GRID) == 0)
     c.close()
+
+
+def test_full_size_properties_c3(E, oracle):
+    """Config C3 at full size (10M points, 1,048,576 queries; the bench workload): size-independent properties.
+      - cell-pruned kernel (with device-side query binning) and brute-force kernel agree bit-for-bit on a
+        4096-query slice, and that slice equals the exhaustive oracle on its first 64 queries;
+      - for ALL 1M queries the reported d2 equals the fp64 distance recomputed on the host to the reported index;
+      - no point of a 1-in-50 subsample of the cloud is closer than the reported neighbour (lower-bound check);
+      - the inflation radii of the 200 C3 seeds equal min(sqrt(d2) - margin, max_radius) and the un-clamped variant."""
+    N, Q = 10_000_000, 1 << 20
+    pts = synth.uniform_points(3, N, 0, 100)
+    q = synth.uniform_points(5, Q, 0, 100)
+    c = make_cloud(E, pts, grid=True)
+    ig, dg = c.nn(q, E.ALGO_GRID)
+    P = pts[ig.astype(np.int64)].astype(np.float64) - q.astype(np.float64)
+    s = P[:, 0] * P[:, 0]; s = s + P[:, 1] * P[:, 1]; s = s + P[:, 2] * P[:, 2]
+    assert np.array_equal(s, dg)
+    ib, db = c.nn(q[:4096], E.ALGO_STREAM)
+    assert np.array_equal(ib, ig[:4096]) and np.array_equal(db, dg[:4096])
+    bi, bd = oracle.brute_nearest(pts, q[:64])
+    assert np.array_equal(dg[:64], bd) and np.array_equal(ig[:64].astype(np.int64), bi.astype(np.int64))
+    _, sd = oracle.brute_nearest(pts[::50], q[:512])
+    assert np.all(dg[:512] <= sd)
+    seeds = synth.uniform_points(4, 200, 10.0, 90.0).astype(np.float64)
+    for max_r in (1.5, 1e9):
+        prm = E.inflate_params((50.0, 50.0, 50.0), 1e9, 0.25, max_r)
+        rad, idx, d2 = c.inflate(prm, seeds)
+        assert np.array_equal(rad, np.minimum(np.sqrt(d2) - 0.25, max_r))
+        si, sd2 = c.nn(seeds.astype(np.float32), E.ALGO_STREAM)
+        assert np.array_equal(si, idx) and np.array_equal(sd2, d2)
+    c.close()
+
+
+def test_rolling_cloud_graph_replan_c5(E, oracle):
+    """Config C5 in miniature: a rolling cloud (ring of 400k points fed 25k per frame, moving along +x), and per
+    tick a hipGraph-captured batch of 164 queries (64 node re-checks + 100 trajectory samples) against the
+    current window, checked against the exhaustive oracle on the same window."""
+    cap, frame = 400_000, 25_000
+    c = E.Cloud(cap)
+    ring = np.zeros((cap, 3), np.float32)
+    nxt = 0
+    def feed(k):
+        nonlocal nxt
+        f = (synth.uniform_points(800 + k, frame, 0, 60) + np.float32([0.1 * k, 0, 0])).astype(np.float32)
+        c.append(f)
+        idx = (nxt + np.arange(frame)) % cap
+        ring[idx] = f
+        nxt = (nxt + frame) % cap
+    for k in range(cap // frame):
+        feed(k)
+    assert len(c) == cap
+    plan = E.NNPlan(c, 164, E.ALGO_STREAM)          # captured once the ring is full (the point count is baked in)
+    for k in range(cap // frame, cap // frame + 5):
+        feed(k)
+        q = (synth.uniform_points(900 + k, 164, 5, 55) + np.float32([0.1 * k, 0, 0])).astype(np.float32)
+        i1, d1 = plan.run(q)
+        bi, bd = oracle.brute_nearest(ring, q)
+        assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64)), f"tick {k}"
+    plan.close()
+    c.close()
