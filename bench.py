@@ -52,6 +52,62 @@ def measured_traffic(kernel: str):
     return best
 
 
+def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
+    """Config C5: rolling window of 5,000,000 points fed 50,000 per sensor frame
+    (uniform in a 60 m cube around a drone moving +0.1 m per frame along x, seed 8), oldest frame evicted.
+    Per tick, through the host-buffer entry points (PCIe + launch latency included), on the un-indexed
+    rolling cloud (brute-force kernels; the cloud changes every tick):
+      ingest   pct_cloud_append_aos of the new frame
+      corridor pct_inflate_batch of 64 corridor nodes (SafeRegionEvaluate's re-check, corridor_finder.cpp:829-835)
+      bezier   pct_bezier_check: 3 segments of order 6, dt 0.02 s over a 2.0 s horizon = 99 samples
+               (checkSafeTrajectory, sim_planning_demo.cpp:729-781)
+    Reported: p50 / p99 milliseconds per tick and per part."""
+    import numpy as np
+    cloud = E.Cloud(window)
+    pos = 0.0
+
+    def frame_pts(k):
+        p = synth.uniform_points(8, frame, -30.0, 30.0, offset=k * frame)
+        p[:, 0] += np.float32(0.1 * k)
+        p[:, 2] = np.abs(p[:, 2]) * np.float32(0.2)
+        return p
+
+    nfill = window // frame
+    for k in range(nfill - 2):
+        cloud.append(frame_pts(k))
+    orders = np.int32([6, 6, 6])
+    seg_time = np.float64([1.0, 1.0, 1.0])
+    t_ing, t_cor, t_bez = [], [], []
+    for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (workspaces, first launches)
+        x0 = 0.1 * k
+        t0 = time.perf_counter()
+        cloud.append(frame_pts(k))
+        t1 = time.perf_counter()
+        nodes = (synth.uniform_points(9, 64, -1.0, 1.0, offset=k * 64).astype(np.float64) * [8.0, 3.0, 1.0] + [x0 + 6.0, 0.0, 2.5])
+        prm = E.inflate_params((x0, 0.0, 2.5), 30.0, 0.25, 1.5)
+        cloud.inflate(prm, nodes)
+        t2 = time.perf_counter()
+        coef = np.zeros((3, 21))
+        ctrl = synth.uniform_points(9, 21, -0.3, 0.3, offset=1_000_000 + k * 21).astype(np.float64)
+        for sgm in range(3):
+            for d in range(3):
+                for j in range(7):
+                    w = (sgm + j / 6.0) / 3.0
+                    base = [x0 + 12.0 * w, 0.0, 2.5][d]
+                    coef[sgm, d * 7 + j] = (base + (ctrl[sgm * 7 + j, d] if 0 < j < 6 else 0.0)) / seg_time[sgm]
+        cloud.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128)
+        t3 = time.perf_counter()
+        if k >= nfill:
+            t_ing.append(1e3 * (t1 - t0)); t_cor.append(1e3 * (t2 - t1)); t_bez.append(1e3 * (t3 - t2))
+    tot = np.asarray(t_ing) + np.asarray(t_cor) + np.asarray(t_bez)
+    cloud.close()
+    pct = lambda a, q: float(np.percentile(a, q))
+    return {"what": "C5: 5,000,000-point rolling cloud, +50,000 points per tick, 64 corridor-node inflations + 99-sample Bezier check per tick, host buffers",
+            "ticks": ticks, "ms_per_tick_p50": pct(tot, 50), "ms_per_tick_p99": pct(tot, 99),
+            "ingest_ms_p50": pct(t_ing, 50), "corridor_inflate_ms_p50": pct(t_cor, 50), "bezier_check_ms_p50": pct(t_bez, 50),
+            "budget_ms_at_20Hz": 50.0}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,7 +119,8 @@ def parse():
     ap.add_argument("--cell", type=float, default=0.0, help="grid cell size (<=0: automatic)")
     ap.add_argument("--cpu-queries", type=int, default=20000, help="queries timed on the host kd-tree (0 = skip)")
     ap.add_argument("--cpu-points", type=int, default=0, help="points in the host kd-tree (0 = same as --points)")
-    ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming kernel at Q=8 (0 = skip)")
+    ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming / brute-force / corridor probes (0 = skip)")
+    ap.add_argument("--replan-probe", type=int, default=1, help="config C5: rolling 5M-point cloud, 20 Hz replan ticks (0 = skip)")
     return ap.parse_args()
 
 
@@ -238,6 +295,9 @@ def main():
             ts.append(1e3 * (time.perf_counter() - t1))
         out["corridor_probe"] = {"what": "pct_inflate_batch, 200 seeds (seed 4), search_margin 0.25, max_radius 1.5, host buffers",
                                  "ms_per_pass_median": float(np.median(ts)), "ms_per_pass_p99": float(np.percentile(ts, 99))}
+
+    if a.replan_probe and world == 1:
+        out["replan_probe"] = replan_probe(E, synth)
 
     if a.cpu_queries > 0 and world == 1:
         ncpu = a.cpu_points or a.points

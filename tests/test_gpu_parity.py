@@ -385,3 +385,19 @@ def test_rolling_cloud_graph_replan_c5(E, oracle):
         assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64)), f"tick {k}"
     plan.close()
     c.close()
+
+
+def test_skewed_query_batches(E, oracle):
+    """Query batches that defeat uniform assumptions of the device-side sort: every query in ONE cell,
+    many exact duplicates, a tight cluster plus far outliers (outside the cloud's bounding box)."""
+    pts = synth.uniform_points(71, 120000, 0, 50)
+    one_cell = (np.float32([25.0, 25.0, 25.0]) + synth.uniform_points(72, 20000, 0, 0.05)).astype(np.float32)
+    dup = np.repeat(synth.uniform_points(73, 50, 0, 50), 400, axis=0)
+    mixed = np.concatenate([(np.float32([10, 40, 5]) + synth.uniform_points(74, 18000, 0, 1.0)).astype(np.float32),
+                            synth.uniform_points(75, 2000, -500, 500)])
+    c = make_cloud(E, pts, grid=True)
+    for q in (one_cell, dup, mixed):
+        bi, bd = oracle.brute_nearest(pts, q)
+        ig, dg = c.nn(q, E.ALGO_GRID)
+        assert np.array_equal(dg, bd) and np.array_equal(ig.astype(np.int64), bi.astype(np.int64))
+    c.close()
