@@ -1,0 +1,42 @@
+/*
+ * pct_corridor.h -- C ABI of libpct_corridor.so: the safe-region RRT* corridor finder
+ * (include/pct_corridor_finder.hpp) for callers that cannot include C++ (tests, bench, cgo/ctypes).
+ *
+ * Replaces, call for call, the planner node's use of safeRegionRrtStar
+ * (Planner/src/sim_planning_demo.cpp:143, 167, 346-347, 350, 354, 367, 399, 412-413, 416, 487, 761;
+ * class surface Planner/include/pointcloudTraj/corridor_finder.h:81-149).  The wall-clock limits of
+ * SafeRegionExpansion/Refine/Evaluate become iteration counts (deterministic runs).
+ */
+#ifndef PCT_CORRIDOR_H
+#define PCT_CORRIDOR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pct_corridor pct_corridor;
+
+int pct_corridor_create(int64_t cloud_capacity, int device, pct_corridor **out);   /* 0 = ok */
+void pct_corridor_destroy(pct_corridor *c);
+const char *pct_corridor_last_error(void);
+
+int pct_corridor_set_param(pct_corridor *c, double safety_margin, double search_margin, double max_radius, double sample_range);
+int pct_corridor_reset(pct_corridor *c);
+int pct_corridor_set_input(pct_corridor *c, const void *points, int64_t n, int64_t stride_bytes, int build_index);
+int pct_corridor_set_pt(pct_corridor *c, const double start[3], const double end[3], double xl, double xh, double yl, double yh,
+                        double zl, double zh, double local_range, int max_iter, double sample_portion, double goal_portion);
+int pct_corridor_set_start_pt(pct_corridor *c, const double start[3], const double end[3]);
+int pct_corridor_reset_root(pct_corridor *c, const double target[3]);
+int pct_corridor_expansion(pct_corridor *c, int64_t iterations);
+int pct_corridor_refine(pct_corridor *c, int64_t iterations);
+int pct_corridor_evaluate(pct_corridor *c);
+int pct_corridor_check_traj_pt_col(pct_corridor *c, const double p[3], int *collides);
+/* Path (k x 3, root first) and Radius (k); k through *n_out (may exceed cap; only cap rows written).
+ * No path: the reference's placeholder, a 3x3 identity and three zero radii. */
+int pct_corridor_get_path(pct_corridor *c, double *path, double *radius, int64_t cap, int64_t *n_out);
+int pct_corridor_status(pct_corridor *c, int *path_exists, int *global_navi, int64_t *n_nodes, uint64_t *inflation_queries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -309,3 +309,83 @@ def check_safe_trajectory(kd: PortKD, params, polycoef, seg_time, orders, t_star
                                          pos.reshape(-1), rad, d2, idx)
     n = ns.value
     return dict(first_hit=int(first), n=int(n), pos=pos[:n], radius=rad[:n], d2=d2[:n], idx=idx[:n])
+
+
+# ---- safe-region RRT* corridor finder (oracle/rrt_port.c) ---------------------------------------------------------
+class PortCorridor:
+    """CPU oracle of the corridor finder; same method names as pointcloudtraj_amd.corridor.SafeRegionRrtStar."""
+
+    def __init__(self):
+        L = port_lib()
+        vp, d3 = C.c_void_p, C.POINTER(C.c_double)
+        L.orrt_create.restype = vp
+        L.orrt_destroy.argtypes = [vp]
+        L.orrt_set_param.argtypes = [vp] + [C.c_double] * 4
+        L.orrt_reset.argtypes = [vp]
+        L.orrt_set_input.argtypes = [vp, _f32p, C.c_int64]
+        L.orrt_set_start_pt.argtypes = [vp, d3, d3]
+        L.orrt_set_pt.argtypes = [vp, d3, d3] + [C.c_double] * 7 + [C.c_int, C.c_double, C.c_double]
+        L.orrt_expansion.argtypes = [vp, C.c_int64]
+        L.orrt_refine.argtypes = [vp, C.c_int64]
+        L.orrt_evaluate.argtypes = [vp]
+        L.orrt_reset_root.argtypes = [vp, d3]
+        L.orrt_check_traj_pt_col.argtypes = [vp, d3]
+        L.orrt_get_path.restype = C.c_int64
+        L.orrt_get_path.argtypes = [vp, _f64p, _f64p, C.c_int64]
+        L.orrt_status.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
+        self.L = L
+        self.h = L.orrt_create()
+
+    @staticmethod
+    def _d3(v):
+        return (C.c_double * 3)(*[float(x) for x in v])
+
+    def close(self):
+        if self.h:
+            self.L.orrt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def setParam(self, safety_margin, search_margin, max_radius, sample_range):
+        self.L.orrt_set_param(self.h, safety_margin, search_margin, max_radius, sample_range)
+
+    def reset(self):
+        self.L.orrt_reset(self.h)
+
+    def setInput(self, points, build_index=True):
+        a = np.ascontiguousarray(np.asarray(points, np.float32)[:, :3])
+        self.L.orrt_set_input(self.h, a, len(a))
+
+    def setPt(self, start, end, xl, xh, yl, yh, zl, zh, local_range, max_iter, sample_portion, goal_portion):
+        self.L.orrt_set_pt(self.h, self._d3(start), self._d3(end), xl, xh, yl, yh, zl, zh, local_range, int(max_iter),
+                           sample_portion, goal_portion)
+
+    def setStartPt(self, start, end):
+        self.L.orrt_set_start_pt(self.h, self._d3(start), self._d3(end))
+
+    def resetRoot(self, target):
+        self.L.orrt_reset_root(self.h, self._d3(target))
+
+    def SafeRegionExpansion(self, iterations):
+        self.L.orrt_expansion(self.h, int(iterations))
+
+    def SafeRegionRefine(self, iterations):
+        self.L.orrt_refine(self.h, int(iterations))
+
+    def SafeRegionEvaluate(self):
+        self.L.orrt_evaluate(self.h)
+
+    def checkTrajPtCol(self, p) -> bool:
+        return bool(self.L.orrt_check_traj_pt_col(self.h, self._d3(p)))
+
+    def getPath(self):
+        path = np.zeros(3 * 4096)
+        rad = np.zeros(4096)
+        n = self.L.orrt_get_path(self.h, path, rad, 4096)
+        return path.reshape(-1, 3)[:n].copy(), rad[:n].copy()
+
+    def status(self):
+        pe, gn, nn, ni = C.c_int(), C.c_int(), C.c_int64(), C.c_uint64()
+        self.L.orrt_status(self.h, C.byref(pe), C.byref(gn), C.byref(nn), C.byref(ni))
+        return dict(path_exists=bool(pe.value), global_navi=bool(gn.value), nodes=nn.value, inflation_queries=ni.value)

@@ -17,6 +17,7 @@ LIB = os.path.join(PKG, "lib")
 ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
 KDTREE_SO = os.path.join(LIB, "libkdtree.so")
 DEMO_BIN = os.path.join(LIB, "seam_demo")
+CORRIDOR_SO = os.path.join(LIB, "libpct_corridor.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -49,6 +50,16 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
         subprocess.run(cmd, check=True)
 
 
+    cor_src = os.path.join(CSRC, "corridor.cpp")
+    cor_hdrs = [os.path.join(ROOT, "include", h) for h in ("pct_corridor.h", "pct_corridor_finder.hpp", "pct_obstacle_map.hpp")]
+    if os.path.exists(cor_src) and os.path.exists(KDTREE_SO) and (force or _stale(CORRIDOR_SO, [cor_src, KDTREE_SO] + cor_hdrs + hdrs)):
+        # host-only C++: the corridor finder's bookkeeping; every distance it needs comes from the two libraries above
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+               "-o", CORRIDOR_SO, cor_src, "-L" + LIB, "-lkdtree", "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
+               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,-soname,libpct_corridor.so"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     demo_src = os.path.join(ROOT, "examples", "seam_demo.cpp")
     if os.path.exists(demo_src) and os.path.exists(KDTREE_SO) and (force or _stale(DEMO_BIN, [demo_src, KDTREE_SO] + hdrs + [os.path.join(ROOT, "include", "pct_obstacle_map.hpp")])):
         # a plain g++ client of the two libraries: the link line INTEGRATION.md gives the planner

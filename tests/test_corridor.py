@@ -1,0 +1,60 @@
+"""Corridor finder: CPU oracle sanity on config C1, and -- on the GPU -- the engine-backed
+finder against the oracle (two independent implementations, no shared code) for the same seed and iteration counts."""
+import numpy as np
+import pytest
+
+from corridor_scenario import GOAL, START, run_scenario, sensed_cloud
+
+
+def check_corridor(path, radius, cloud, safety=0.6):
+    """a corridor is a chain of overlapping safe spheres from the start to the goal"""
+    assert len(path) >= 2
+    assert np.linalg.norm(path[0] - np.float64(START)) < 1e-9
+    assert np.linalg.norm(path[-1] - np.float64(GOAL)) + 0.1 < radius[-1]            # checkEnd, corridor_finder.cpp:418-426
+    assert np.all(radius >= np.float32(safety))
+    for a, b, ra, rb in zip(path[:-1], path[1:], radius[:-1], radius[1:]):
+        assert np.linalg.norm(a - b) + 0.1 < 0.95 * (np.float32(ra) + np.float32(rb)) + 1e-6   # checkNodeRelation == -1
+    c64 = cloud.astype(np.float64)
+    for p, r in zip(path, radius):                                                   # every sphere is free of obstacle points
+        assert np.sqrt(((c64 - p) ** 2).sum(1).min()) >= r + 0.25 - 1e-6
+
+
+def test_oracle_corridor_c1(oracle):
+    from corridor_scenario import perturbed_cloud
+    cloud1 = sensed_cloud(12.0)
+    for cloud2 in (None, sensed_cloud(16.0)):       # a mild change (corridor survives, radii shrink) and a drastic one
+        f = oracle.PortCorridor()
+        phases = run_scenario(f, cloud1, cloud2)
+        (p0, r0, s0), (p1, r1, s1), (p2, r2, s2), (p3, r3, s3) = phases
+        c2 = perturbed_cloud(cloud1, p1) if cloud2 is None else cloud2
+        assert s0["path_exists"] and s1["path_exists"]
+        check_corridor(p0, r0, cloud1)
+        check_corridor(p1, r1, cloud1)
+        assert s0["nodes"] > 20 and s0["inflation_queries"] > 500
+        if cloud2 is None:
+            assert s2["path_exists"], "the mild perturbation must leave a corridor"
+            assert not np.array_equal(r1, r2) or not np.array_equal(p1, p2)
+        if s2["path_exists"]:
+            check_corridor(p2, r2, c2)
+        if s3["path_exists"]:
+            check_corridor(p3, r3, c2)
+        # deterministic: a second run reproduces the corridor bit for bit
+        again = run_scenario(oracle.PortCorridor(), cloud1, cloud2)
+        for (pa, ra, _), (pb, rb, _) in zip(phases, again):
+            assert np.array_equal(pa, pb) and np.array_equal(ra, rb)
+
+
+@pytest.mark.gpu
+def test_gpu_corridor_matches_oracle(oracle):
+    from pointcloudtraj_amd import corridor, engine
+    engine.init(0)
+    cloud1 = sensed_cloud(12.0)
+    for cloud2 in (None, sensed_cloud(16.0)):
+        want = run_scenario(oracle.PortCorridor(), cloud1, cloud2, expand=600, refine=200)
+        got = run_scenario(corridor.SafeRegionRrtStar(80000), cloud1, cloud2, expand=600, refine=200)
+        for k, ((pw, rw, sw), (pg, rg, sg)) in enumerate(zip(want, got)):
+            assert sw["path_exists"] == sg["path_exists"] and sw["nodes"] == sg["nodes"], f"phase {k}: {sw} vs {sg}"
+            assert np.array_equal(pw, pg), f"phase {k}: corridor centres differ"
+            assert np.array_equal(rw, rg), f"phase {k}: corridor radii differ"
+            assert sw["inflation_queries"] == sg["inflation_queries"]
+        assert want[0][2]["path_exists"]
