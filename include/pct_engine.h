@@ -65,6 +65,9 @@ int pct_sync(void);                             /* wait for everything queued by
 
 /* ---- cloud lifecycle ----------------------------------------------------------------- */
 int pct_cloud_create(int64_t capacity, pct_cloud **out);
+/* a cloud whose coordinates live in host-mapped memory: appends are plain host stores (no launch, no copy),
+ * kernels read over the bus.  For small, frequently growing point sets (the RRT* node tree behind kd_*). */
+int pct_cloud_create_small(int64_t capacity, pct_cloud **out);
 int pct_cloud_destroy(pct_cloud *c);
 int64_t pct_cloud_size(const pct_cloud *c);
 int64_t pct_cloud_capacity(const pct_cloud *c);

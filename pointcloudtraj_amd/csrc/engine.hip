@@ -72,12 +72,36 @@ void dev_free(T *&p)
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+constexpr int kExpressMaxQ = 64;          // queries per express inflation launch
+constexpr int64_t kSmallNNMax = 16384;    // clouds up to this size answer single queries with one-block kernels
+constexpr uint32_t kExpressIdsCap = 1u << 16;
+
+template <typename T>
+int mapped_alloc(T **host, T **dev, size_t count)
+{
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, std::max<size_t>(count, 1) * sizeof(T), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { if (h) (void)hipHostFree(h); return fail(PCT_ERR_ALLOC, "hipHostMalloc(mapped, %zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e)); }
+    *host = static_cast<T *>(h);
+    *dev = static_cast<T *>(d);
+    return PCT_OK;
+}
+
 }  // namespace
 
 struct pct_cloud {
     int64_t cap = 0, cap4 = 0, count = 0, ring_next = 0;
     int64_t index_base = 0;
     float *x = nullptr, *y = nullptr, *z = nullptr;
+    // "small" clouds keep their coordinates in host-mapped memory (kernels read them over the bus; the host
+    // appends with plain stores and no launch) -- the RRT* node sets of the kd_* drop-in
+    bool host_mapped = false;
+    float *hx = nullptr, *hy = nullptr, *hz = nullptr;
+    // express path: host-mapped result / argument / id buffers
+    ExpressOut *h_xout = nullptr, *d_xout = nullptr;
+    double *h_xin = nullptr, *d_xin = nullptr;
+    uint32_t *h_xids = nullptr, *d_xids = nullptr;
     unsigned char *d_stage = nullptr;
     size_t stage_bytes = 0;
     // grid
@@ -156,6 +180,14 @@ void drop_grid(pct_cloud *c) { c->has_grid = false; }
 int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64_t dst0)
 {
     if (n == 0) return PCT_OK;
+    if (c->host_mapped) {   // plain host stores; every earlier kernel on this cloud has been waited for
+        const unsigned char *src = static_cast<const unsigned char *>(pts);
+        for (int64_t i = 0; i < n; i++) {
+            const float *p = reinterpret_cast<const float *>(src + i * stride);
+            c->hx[dst0 + i] = p[0]; c->hy[dst0 + i] = p[1]; c->hz[dst0 + i] = p[2];
+        }
+        return PCT_OK;
+    }
     PCTCHK(ensure_stage(c, (size_t)n * stride + 64));
     HIPCHK(hipMemcpyAsync(c->d_stage, pts, (size_t)n * stride, hipMemcpyHostToDevice, g_stream));
     if (stride == 12 && (dst0 & 3) == 0 && n >= 4) {
@@ -490,7 +522,7 @@ int pct_sync(void)
     return PCT_OK;
 }
 
-int pct_cloud_create(int64_t capacity, pct_cloud **out)
+static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out)
 {
     if (!out || capacity < 0 || capacity > 0xFFFFFFF0ll) return fail(PCT_ERR_INVALID, "bad capacity");
     PCTCHK(require_init());
@@ -498,11 +530,20 @@ int pct_cloud_create(int64_t capacity, pct_cloud **out)
     if (!c) return fail(PCT_ERR_ALLOC, "host allocation failed");
     c->cap = capacity;
     c->cap4 = (capacity + 3) & ~3ll;
+    c->host_mapped = host_mapped;
     int s;
-    if ((s = dev_alloc(&c->x, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->y, (size_t)c->cap4 + 4)) ||
-        (s = dev_alloc(&c->z, (size_t)c->cap4 + 4)) || (s = dev_alloc(&c->d_work, kWorkSlots))) {
+    if (host_mapped)
+        s = mapped_alloc(&c->hx, &c->x, (size_t)c->cap4 + 4) || mapped_alloc(&c->hy, &c->y, (size_t)c->cap4 + 4) ||
+            mapped_alloc(&c->hz, &c->z, (size_t)c->cap4 + 4);
+    else
+        s = dev_alloc(&c->x, (size_t)c->cap4 + 4) || dev_alloc(&c->y, (size_t)c->cap4 + 4) || dev_alloc(&c->z, (size_t)c->cap4 + 4);
+    if (!s) s = dev_alloc(&c->d_work, kWorkSlots);
+    if (!s) s = mapped_alloc(&c->h_xout, &c->d_xout, kExpressMaxQ);
+    if (!s) s = mapped_alloc(&c->h_xin, &c->d_xin, 3 * kExpressMaxQ);
+    if (!s) s = mapped_alloc(&c->h_xids, &c->d_xids, kExpressIdsCap);
+    if (s) {
         pct_cloud_destroy(c);
-        return s;
+        return PCT_ERR_ALLOC;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess ||
         hipEventCreate(&c->ev3) != hipSuccess) {
@@ -513,10 +554,27 @@ int pct_cloud_create(int64_t capacity, pct_cloud **out)
     return PCT_OK;
 }
 
+int pct_cloud_create(int64_t capacity, pct_cloud **out) { return cloud_create_impl(capacity, false, out); }
+
+int pct_cloud_create_small(int64_t capacity, pct_cloud **out)
+{
+    if (capacity > (1ll << 22)) return fail(PCT_ERR_INVALID, "small (host-mapped) clouds hold at most 4M points");
+    return cloud_create_impl(capacity, true, out);
+}
+
 int pct_cloud_destroy(pct_cloud *c)
 {
     if (!c) return PCT_OK;
     if (g_stream) (void)hipStreamSynchronize(g_stream);
+    if (c->host_mapped) {
+        if (c->hx) (void)hipHostFree(c->hx);
+        if (c->hy) (void)hipHostFree(c->hy);
+        if (c->hz) (void)hipHostFree(c->hz);
+        c->x = c->y = c->z = nullptr;
+    }
+    if (c->h_xout) (void)hipHostFree(c->h_xout);
+    if (c->h_xin) (void)hipHostFree(c->h_xin);
+    if (c->h_xids) (void)hipHostFree(c->h_xids);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
@@ -800,6 +858,14 @@ int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, do
         for (int64_t i = 0; i < Q; i++) { idx[i] = PCT_NO_INDEX; d2[i] = INFINITY; }
         return fail(PCT_ERR_EMPTY, "nearest-neighbour query against an empty cloud");
     }
+    if (Q == 1 && c->count <= kSmallNNMax) {   // express: one one-block launch, query by value, result in mapped memory
+        nn_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], (uint32_t)c->index_base, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        idx[0] = c->h_xout[0].idx;
+        d2[0] = c->h_xout[0].d2;
+        return PCT_OK;
+    }
     // The fp32 filter is only valid when the query coordinates themselves are fp32 values
     // (always the case for kd_nearestf); genuinely double queries take the all-fp64 kernel.
     bool f32_exact = true;
@@ -850,6 +916,17 @@ int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *
     if (!c || !q || cap < 0 || (cap > 0 && !idx_out) || !n_out) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
     *n_out = 0;
     if (c->count == 0) return PCT_OK;
+    if (c->count <= 4 * kSmallNNMax && c->count <= (int64_t)kExpressIdsCap) {   // express: one launch, ids in mapped memory
+        radius_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], r * r, (uint32_t)c->index_base,
+                                                       c->d_xids, kExpressIdsCap, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        const int64_t total = c->h_xout[0].count, got = std::min<int64_t>(total, cap);
+        std::copy(c->h_xids, c->h_xids + std::min<int64_t>(got, kExpressIdsCap), idx_out);
+        std::sort(idx_out, idx_out + got);
+        *n_out = total;
+        return PCT_OK;
+    }
     uint32_t *d_out = nullptr, *d_cursor = nullptr;
     PCTCHK(dev_alloc(&d_out, (size_t)std::max<int64_t>(cap, 1)));
     int st = dev_alloc(&d_cursor, 1);
@@ -875,6 +952,21 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
 {
     if (!c || !p || Q < 0 || (Q > 0 && (!pts || !radius))) return fail(PCT_ERR_INVALID, "bad inflate arguments");
     if (Q == 0) return PCT_OK;
+    if (Q <= kExpressMaxQ && c->has_grid && c->count > 0) {   // express: one fused launch (a block per point), arguments and results in mapped memory
+        std::memcpy(c->h_xin, pts, sizeof(double) * 3 * Q);
+        // idx / d2 not wanted: the search may stop once everything unseen is beyond max_radius + search_margin
+        const double reach = p->max_radius + p->search_margin;
+        const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
+        inflate_block_kernel<<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, to_dev(p), c->d_xin, stop_d2, (uint32_t)c->index_base, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int64_t i = 0; i < Q; i++) {
+            radius[i] = c->h_xout[i].radius;
+            if (idx) idx[i] = c->h_xout[i].idx;
+            if (d2) d2[i] = c->h_xout[i].d2;
+        }
+        return PCT_OK;
+    }
     PCTCHK(pct_cloud_reserve_queries(c, Q));
     HIPCHK(hipMemcpyAsync(c->d_pts64, pts, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
     PCTCHK(inflate_dev(c, p, Q, g_stream));

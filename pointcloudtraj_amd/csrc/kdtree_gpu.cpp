@@ -73,7 +73,10 @@ int sync_device(kdtree *t)
     if (!t->cloud) {
         int64_t cap = 1024;
         while (cap < n) cap *= 2;
-        if (pct_cloud_create(cap, &t->cloud) != PCT_OK) { complain("pct_cloud_create"); t->cloud = nullptr; return -1; }
+        // node sets up to 64k live in host-mapped memory (kd_insert* costs no launch; single queries take the
+        // one-launch express kernels); larger trees move to a device-resident cloud
+        const int st = cap <= 65536 ? pct_cloud_create_small(cap, &t->cloud) : pct_cloud_create(cap, &t->cloud);
+        if (st != PCT_OK) { complain("pct_cloud_create"); t->cloud = nullptr; return -1; }
         t->synced = 0;
     }
     if (t->synced < n) {

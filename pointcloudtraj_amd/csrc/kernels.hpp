@@ -1086,6 +1086,149 @@ __device__ __forceinline__ void coop_scan_exact(const float4 *__restrict__ pts, 
     }
 }
 
+// The search itself, shared by the batch kernel and the low-latency inflation kernel: all 8 lanes of
+// a group call it with the same query and their own `sub`; every lane returns the same (bd, bi).
+template <bool COUNT>
+__device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *__restrict__ pts,
+                                               const uint32_t *__restrict__ cell_start, float qxf, float qyf, float qzf,
+                                               uint32_t sub, double &bd, uint32_t &bi, uint32_t &npts, uint32_t &nruns)
+{
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
+    const double slack = G.hd * (1.0 / 256.0);
+    {   // ---- first cube: 3x3x3 cells = 9 x-runs ----
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
+        // lane `sub` fetches row `sub`'s bounds, lane 0 also row 8
+        uint32_t my_s = 0, my_e = 0, s8 = 0, e8 = 0;
+        {
+            const int zz = cz + (int)sub / 3 - 1, yy = cy + (int)sub % 3 - 1;
+            const bool ok = zz >= 0 && zz < G.gz && yy >= 0 && yy < G.gy;
+            const uint32_t row = ok ? cell_lin(G, 0, yy, zz) : 0u;
+            const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
+            my_s = a;
+            my_e = ok ? b : a;
+            const int z8 = cz + 1, y8 = cy + 1;
+            const bool ok8 = z8 < G.gz && y8 < G.gy;
+            const uint32_t row8 = ok8 ? cell_lin(G, 0, y8, z8) : 0u;
+            const uint32_t a8 = cell_start[row8 + x0], b8 = cell_start[row8 + x1 + 1];   // same address in all 8 lanes: one access
+            s8 = a8;
+            e8 = ok8 ? b8 : a8;
+            if (COUNT && sub == 0) {
+                npts += e8 - s8; nruns += ok8 ? 1u : 0u;
+            }
+            if (COUNT) {
+                // every lane adds its own row; summed over the wave at the end
+                npts += my_e - my_s; nruns += ok ? 1u : 0u;
+            }
+        }
+        uint32_t rs[9], re[9];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
+        rs[8] = s8; re[8] = e8;
+
+        float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+        uint32_t p1 = 0;
+        // all nine rows are requested before any is consumed (the kernel is bound by dependent
+        // memory round trips: one for the bounds, one for the points)
+        float4 P[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const uint32_t a = rs[k], b = re[k];
+            const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
+            P[k] = pts[min(a + sub, last)];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const uint32_t a = rs[k], b = re[k];
+            const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            d = (a + sub < b) ? d : __builtin_huge_valf();
+            const bool lt = d < m1;
+            m2 = lt ? m1 : fminf(m2, d);
+            p1 = lt ? a + sub : p1;
+            m1 = fminf(m1, d);
+        }
+#pragma unroll 1
+        for (int k = 0; k < 9; k++) {                                // rows longer than 8 points
+            const uint32_t b = re[k];
+            for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
+                const float4 Pp = pts[p];
+                const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
+                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                const bool lt = d < m1;
+                m2 = lt ? m1 : fminf(m2, d);
+                p1 = lt ? p : p1;
+                m1 = fminf(m1, d);
+            }
+        }
+        // fold (smallest, runner-up, position) over the 8 lanes
+#pragma unroll
+        for (int off = 1; off < kCoop; off <<= 1) {
+            const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
+            const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
+            const bool lt = o1 < m1;
+            m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
+            p1 = lt ? op : p1;
+            m1 = fminf(m1, o1);
+        }
+        if (m1 < __builtin_huge_valf()) {
+            if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {            // unique within the fp32 error band: it is the exact winner
+                const float4 P = pts[p1];
+                bd = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
+                bi = __float_as_uint(P.w);
+            } else {                                                  // near-ties / duplicates: exact (d2, index) order decides
+#pragma unroll 1
+                for (int k = 0; k < 9; k++) coop_scan_exact(pts, rs[k], re[k], sub, qx, qy, qz, bd, bi);
+                coop_argmin8(bd, bi);
+            }
+        }
+    }
+    for (int r = 1;; r++) {
+        if (r > 1) {   // ---- shell r (rare): rows walked in the same order by the whole group ----
+            const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
+            const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
+            const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
+            for (int zz = z0; zz <= z1; zz++) {
+                const bool zface = (zz == cz - r) || (zz == cz + r);
+                for (int yy = y0; yy <= y1; yy++) {
+                    const uint32_t row = cell_lin(G, 0, yy, zz);
+                    if (zface || yy == cy - r || yy == cy + r) {
+                        const uint32_t s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                        if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                        coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                    } else {
+                        if (cx - r >= 0) {
+                            const uint32_t s = cell_start[row + cx - r], e = cell_start[row + cx - r + 1];
+                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                        }
+                        if (cx + r <= G.gx - 1) {
+                            const uint32_t s = cell_start[row + cx + r], e = cell_start[row + cx + r + 1];
+                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                        }
+                    }
+                }
+            }
+            coop_argmin8(bd, bi);
+        }
+        double bound = __builtin_huge_val();
+        if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
+        if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
+        if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
+        if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
+        if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
+        if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
+        if (bound == __builtin_huge_val()) break;
+        bound -= slack;
+        if (bound > 0.0 && bd <= bound * bound) break;
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                            const uint32_t *__restrict__ cell_start,
@@ -1107,140 +1250,9 @@ __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const flo
         } else {
             qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
         }
-        const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
-        const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
-        const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
-        const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
-        double bd = __builtin_huge_val();
-        uint32_t bi = kNoIndex;
-        const double slack = G.hd * (1.0 / 256.0);
-        {   // ---- first cube: 3x3x3 cells = 9 x-runs ----
-            const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
-            // lane `sub` fetches row `sub`'s bounds, lane 0 also row 8
-            uint32_t my_s = 0, my_e = 0, s8 = 0, e8 = 0;
-            {
-                const int zz = cz + (int)sub / 3 - 1, yy = cy + (int)sub % 3 - 1;
-                const bool ok = zz >= 0 && zz < G.gz && yy >= 0 && yy < G.gy;
-                const uint32_t row = ok ? cell_lin(G, 0, yy, zz) : 0u;
-                const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
-                my_s = a;
-                my_e = ok ? b : a;
-                const int z8 = cz + 1, y8 = cy + 1;
-                const bool ok8 = z8 < G.gz && y8 < G.gy;
-                const uint32_t row8 = ok8 ? cell_lin(G, 0, y8, z8) : 0u;
-                const uint32_t a8 = cell_start[row8 + x0], b8 = cell_start[row8 + x1 + 1];   // same address in all 8 lanes: one access
-                s8 = a8;
-                e8 = ok8 ? b8 : a8;
-                if (COUNT && sub == 0) {
-                    npts += e8 - s8; nruns += ok8 ? 1u : 0u;
-                }
-                if (COUNT) {
-                    // every lane adds its own row; summed over the wave at the end
-                    npts += my_e - my_s; nruns += ok ? 1u : 0u;
-                }
-            }
-            uint32_t rs[9], re[9];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
-            rs[8] = s8; re[8] = e8;
-
-            float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
-            uint32_t p1 = 0;
-            // all nine rows are requested before any is consumed (the kernel is bound by dependent
-            // memory round trips: one for the bounds, one for the points)
-            float4 P[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const uint32_t a = rs[k], b = re[k];
-                const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
-                P[k] = pts[min(a + sub, last)];
-            }
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const uint32_t a = rs[k], b = re[k];
-                const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
-                float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                d = (a + sub < b) ? d : __builtin_huge_valf();
-                const bool lt = d < m1;
-                m2 = lt ? m1 : fminf(m2, d);
-                p1 = lt ? a + sub : p1;
-                m1 = fminf(m1, d);
-            }
-#pragma unroll 1
-            for (int k = 0; k < 9; k++) {                                // rows longer than 8 points
-                const uint32_t b = re[k];
-                for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
-                    const float4 Pp = pts[p];
-                    const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
-                    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    const bool lt = d < m1;
-                    m2 = lt ? m1 : fminf(m2, d);
-                    p1 = lt ? p : p1;
-                    m1 = fminf(m1, d);
-                }
-            }
-            // fold (smallest, runner-up, position) over the 8 lanes
-#pragma unroll
-            for (int off = 1; off < kCoop; off <<= 1) {
-                const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
-                const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
-                const bool lt = o1 < m1;
-                m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
-                p1 = lt ? op : p1;
-                m1 = fminf(m1, o1);
-            }
-            if (m1 < __builtin_huge_valf()) {
-                if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {            // unique within the fp32 error band: it is the exact winner
-                    const float4 P = pts[p1];
-                    bd = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
-                    bi = __float_as_uint(P.w);
-                } else {                                                  // near-ties / duplicates: exact (d2, index) order decides
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) coop_scan_exact(pts, rs[k], re[k], sub, qx, qy, qz, bd, bi);
-                    coop_argmin8(bd, bi);
-                }
-            }
-        }
-        for (int r = 1;; r++) {
-            if (r > 1) {   // ---- shell r (rare): rows walked in the same order by the whole group ----
-                const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
-                const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
-                const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
-                for (int zz = z0; zz <= z1; zz++) {
-                    const bool zface = (zz == cz - r) || (zz == cz + r);
-                    for (int yy = y0; yy <= y1; yy++) {
-                        const uint32_t row = cell_lin(G, 0, yy, zz);
-                        if (zface || yy == cy - r || yy == cy + r) {
-                            const uint32_t s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                        } else {
-                            if (cx - r >= 0) {
-                                const uint32_t s = cell_start[row + cx - r], e = cell_start[row + cx - r + 1];
-                                if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                                coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                            }
-                            if (cx + r <= G.gx - 1) {
-                                const uint32_t s = cell_start[row + cx + r], e = cell_start[row + cx + r + 1];
-                                if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                                coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                            }
-                        }
-                    }
-                }
-                coop_argmin8(bd, bi);
-            }
-            double bound = __builtin_huge_val();
-            if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
-            if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
-            if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
-            if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
-            if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
-            if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
-            if (bound == __builtin_huge_val()) break;
-            bound -= slack;
-            if (bound > 0.0 && bd <= bound * bound) break;
-        }
+        double bd;
+        uint32_t bi;
+        coop_nn_search<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
         if (sub == 0) {
             out_idx[t] = (bi == kNoIndex) ? kNoIndex : bi + index_base;
             out_d2[t] = bd;
@@ -1307,6 +1319,56 @@ __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float
 }
 
 // =====================================================================================
+// 4b. Low-latency ("express") kernels: ONE launch per call, query passed by value or read from
+//     host-mapped memory, results written straight to host-mapped memory.  The planner's RRT*
+//     loop issues single queries in sequence (corridor_finder.cpp:719-756); there the cost is
+//     launch + copy latency, not throughput.
+// =====================================================================================
+struct ExpressOut { double d2; double radius; uint32_t idx; uint32_t count; };
+
+// one block, exact fp64 brute force over a small cloud (the RRT* node set of the kd_* drop-in)
+__global__ __launch_bounds__(1024) void nn_small_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                        const float *__restrict__ z, uint32_t n, double qx, double qy, double qz,
+                                                        uint32_t index_base, ExpressOut *__restrict__ out)
+{
+    double bd = __builtin_huge_val();
+    uint32_t bi = kNoIndex;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) {
+        const double d2 = dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz);
+        if (d2 < bd) { bd = d2; bi = i; }
+    }
+    wave_argmin(bd, bi);
+    __shared__ double s_d[16];
+    __shared__ uint32_t s_i[16];
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = bd; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++)
+            if (better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
+        out->d2 = bd;
+        out->idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+    }
+}
+
+// one block: ids of all points with d2 <= r2 (arrival order; the host sorts), count in out->count
+__global__ __launch_bounds__(1024) void radius_small_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                            const float *__restrict__ z, uint32_t n, double qx, double qy, double qz,
+                                                            double r2, uint32_t index_base, uint32_t *__restrict__ ids, uint32_t cap,
+                                                            ExpressOut *__restrict__ out)
+{
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 1024)
+        if (dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz) <= r2) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            if (pos < cap) ids[pos] = i + index_base;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) out->count = s_n;
+}
+
+// =====================================================================================
 // 5. Planner arithmetic around the NN: sphere inflation and the sampled Bezier check
 // =====================================================================================
 struct InflateParams { double sx, sy, sz, sample_range, search_margin, max_radius; };
@@ -1345,6 +1407,85 @@ __global__ __launch_bounds__(256) void inflate_epilogue_kernel(InflateParams P, 
     }
     const double r = sqrt(d2[i]) - P.search_margin;
     radius[i] = r < P.max_radius ? r : P.max_radius;
+}
+
+// Block-wide winner: every thread passes its (d2, index) and gets back the block's best.
+__device__ __forceinline__ void block_argmin256(double &d, uint32_t &i, double *s_d, uint32_t *s_i)
+{
+    wave_argmin(d, i);
+    __syncthreads();                                   // previous use of s_d / s_i is over
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    d = s_d[0]; i = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++)
+        if (better(s_d[w], s_i[w], d, i)) { d = s_d[w]; i = s_i[w]; }
+}
+
+// Low-latency fused inflation: ONE 256-thread block per planner point (early-out test, narrowing, cell
+// search, radius), arguments and results in host-mapped memory.  A single query has no batch to hide
+// latency behind, so the parallelism goes across the ROWS of the cube / shell being searched: the 32
+// groups of 8 lanes each take every 32nd row, and the block folds its candidates after each shell.
+// stop_d2: when only the radius is wanted the search may stop once everything unseen is farther than
+// max_radius + search_margin (the radius is then max_radius whatever lies beyond); +inf = exact NN.
+// Same arithmetic and the same termination bound as coop_nn_search.
+__global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const float4 *__restrict__ pts,
+                                                            const uint32_t *__restrict__ cell_start, InflateParams P,
+                                                            const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
+                                                            ExpressOut *__restrict__ out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const uint32_t slot = blockIdx.x, sub = threadIdx.x & (kCoop - 1), grp = threadIdx.x / kCoop;   // 32 groups
+    const double px = qpts[3 * slot], py = qpts[3 * slot + 1], pz = qpts[3 * slot + 2];
+    {
+        const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
+        if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {      // corridor_finder.cpp:115-116
+            if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
+            return;
+        }
+    }
+    const float qxf = (float)px, qyf = (float)py, qzf = (float)pz;                    // searchPoint.x = search_Pt(0), :125-128
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+    const double slack = G.hd * (1.0 / 256.0);
+    double bd = __builtin_huge_val();
+    uint32_t bi = kNoIndex;
+    for (int r = 1;; r++) {
+        const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
+        const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
+        const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        for (int k = (int)grp; k < nrows; k += 256 / kCoop) {
+            const int zz = z0 + k / ny, yy = y0 + k % ny;
+            const uint32_t row = cell_lin(G, 0, yy, zz);
+            if (r == 1 || zz == cz - r || zz == cz + r || yy == cy - r || yy == cy + r) {
+                coop_scan_exact(pts, cell_start[row + x0], cell_start[row + x1 + 1], sub, qx, qy, qz, bd, bi);
+            } else {
+                if (cx - r >= 0) coop_scan_exact(pts, cell_start[row + cx - r], cell_start[row + cx - r + 1], sub, qx, qy, qz, bd, bi);
+                if (cx + r <= G.gx - 1) coop_scan_exact(pts, cell_start[row + cx + r], cell_start[row + cx + r + 1], sub, qx, qy, qz, bd, bi);
+            }
+        }
+        block_argmin256(bd, bi, s_d, s_i);
+        double bound = __builtin_huge_val();
+        if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
+        if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
+        if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
+        if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
+        if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
+        if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
+        if (bound == __builtin_huge_val()) break;
+        bound -= slack;
+        if (bound > 0.0 && (bd <= bound * bound || bound * bound >= stop_d2)) break;
+    }
+    if (threadIdx.x == 0) {
+        const double rr = sqrt(bd) - P.search_margin;
+        out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        out[slot].d2 = bd;
+    }
 }
 
 constexpr int kMaxBezierOrder = 12;
