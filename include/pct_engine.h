@@ -78,6 +78,9 @@ int pct_cloud_set_index_base(pct_cloud *c, int64_t base);
  * each `stride_bytes` record (12 = packed, 16 = pcl::PointXYZ).  De-interleaved to SoA on
  * the device.  Drops any grid. */
 int pct_cloud_upload_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes);
+/* Same for a sensor_msgs/PointCloud2 payload: n records of point_step bytes, FLOAT32 fields at the given byte
+ * offsets (msg.fields[i].offset), any order, any padding (sim_planning_demo.cpp:159-167). */
+int pct_cloud_upload_fields(pct_cloud *c, const void *data, int64_t n, int64_t point_step, int64_t off_x, int64_t off_y, int64_t off_z);
 /* Same, from three device arrays (already SoA, e.g. produced on the GPU). */
 int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n);
 /* Rolling map: append n points, overwriting the oldest once capacity is reached (ring).

@@ -72,7 +72,7 @@ void dev_free(T *&p)
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-constexpr int kExpressMaxQ = 64;          // queries per express inflation launch
+constexpr int kExpressMaxQ = 1024;        // queries per express (block-per-query) launch
 constexpr int64_t kSmallNNMax = 16384;    // clouds up to this size answer single queries with one-block kernels
 constexpr uint32_t kExpressIdsCap = 1u << 16;
 
@@ -613,6 +613,26 @@ int pct_cloud_upload_aos(pct_cloud *c, const void *pts, int64_t n, int64_t strid
     return PCT_OK;
 }
 
+// sensor_msgs/PointCloud2 (rcvPointCloudCallBack, sim_planning_demo.cpp:159-167): a byte blob of `n` records of
+// `point_step` bytes whose FLOAT32 fields x, y, z sit at arbitrary byte offsets.  Records are repacked on the host
+// into 12-byte xyz (one pass; the message is pageable host memory anyway) and take the packed upload path.
+int pct_cloud_upload_fields(pct_cloud *c, const void *data, int64_t n, int64_t point_step, int64_t off_x, int64_t off_y, int64_t off_z)
+{
+    if (!c || n < 0 || (n > 0 && !data) || point_step < 4 || off_x < 0 || off_y < 0 || off_z < 0 || off_x + 4 > point_step ||
+        off_y + 4 > point_step || off_z + 4 > point_step)
+        return fail(PCT_ERR_INVALID, "bad upload_fields arguments");
+    if (off_x == 0 && off_y == 4 && off_z == 8 && (point_step & 3) == 0 && point_step >= 12) return pct_cloud_upload_aos(c, data, n, point_step);
+    std::vector<float> packed;
+    try { packed.resize((size_t)3 * n); } catch (const std::bad_alloc &) { return fail(PCT_ERR_ALLOC, "host allocation failed"); }
+    const unsigned char *src = static_cast<const unsigned char *>(data);
+    for (int64_t i = 0; i < n; i++) {
+        std::memcpy(&packed[3 * i], src + i * point_step + off_x, 4);
+        std::memcpy(&packed[3 * i + 1], src + i * point_step + off_y, 4);
+        std::memcpy(&packed[3 * i + 2], src + i * point_step + off_z, 4);
+    }
+    return pct_cloud_upload_aos(c, packed.data(), n, 12);
+}
+
 int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n)
 {
     if (!c || n < 0 || (n > 0 && (!d_x || !d_y || !d_z))) return fail(PCT_ERR_INVALID, "bad upload arguments");
@@ -834,6 +854,16 @@ int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_
 {
     if (!c || Q < 0 || (Q > 0 && (!q || !idx || !d2))) return fail(PCT_ERR_INVALID, "bad nn_batch arguments");
     if (Q == 0) return PCT_OK;
+    if (Q <= kExpressMaxQ && c->has_grid && c->count > 0 && (algo == PCT_ALGO_AUTO || algo == PCT_ALGO_GRID)) {
+        // small batch on an indexed cloud: one launch, a block per query, arguments/results in mapped memory
+        for (int64_t i = 0; i < 3 * Q; i++) c->h_xin[i] = (double)q[i];
+        inflate_block_kernel<false><<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, InflateParams{}, c->d_xin, (double)INFINITY,
+                                                                   (uint32_t)c->index_base, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
+        return PCT_OK;
+    }
     PCTCHK(pct_cloud_reserve_queries(c, Q));
     HIPCHK(hipMemcpyAsync(c->d_q, q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
     PCTCHK(nn_dev(c, algo, c->d_q, Q, c->d_idx, c->d_d2, g_stream));
@@ -957,7 +987,7 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
         // idx / d2 not wanted: the search may stop once everything unseen is beyond max_radius + search_margin
         const double reach = p->max_radius + p->search_margin;
         const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
-        inflate_block_kernel<<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, to_dev(p), c->d_xin, stop_d2, (uint32_t)c->index_base, c->d_xout);
+        inflate_block_kernel<true><<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, to_dev(p), c->d_xin, stop_d2, (uint32_t)c->index_base, c->d_xout);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g_stream));
         for (int64_t i = 0; i < Q; i++) {

@@ -1429,6 +1429,8 @@ __device__ __forceinline__ void block_argmin256(double &d, uint32_t &i, double *
 // stop_d2: when only the radius is wanted the search may stop once everything unseen is farther than
 // max_radius + search_margin (the radius is then max_radius whatever lies beyond); +inf = exact NN.
 // Same arithmetic and the same termination bound as coop_nn_search.
+// INFLATE = false: plain nearest neighbour of the (fp32-valued) points in qpts -- no early-out, no radius.
+template <bool INFLATE>
 __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                             const uint32_t *__restrict__ cell_start, InflateParams P,
                                                             const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
@@ -1438,7 +1440,7 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const fl
     __shared__ uint32_t s_i[4];
     const uint32_t slot = blockIdx.x, sub = threadIdx.x & (kCoop - 1), grp = threadIdx.x / kCoop;   // 32 groups
     const double px = qpts[3 * slot], py = qpts[3 * slot + 1], pz = qpts[3 * slot + 2];
-    {
+    if (INFLATE) {
         const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
         if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {      // corridor_finder.cpp:115-116
             if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
@@ -1481,8 +1483,10 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const fl
         if (bound > 0.0 && (bd <= bound * bound || bound * bound >= stop_d2)) break;
     }
     if (threadIdx.x == 0) {
-        const double rr = sqrt(bd) - P.search_margin;
-        out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        if (INFLATE) {
+            const double rr = sqrt(bd) - P.search_margin;
+            out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        }
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
     }

@@ -71,6 +71,7 @@ def lib():
         L.pct_cloud_set_index_base.argtypes = [vp, i64]
         L.pct_cloud_upload_aos.argtypes = [vp, vp, i64, i64]
         L.pct_cloud_upload_soa_dev.argtypes = [vp, vp, vp, vp, i64]
+        L.pct_cloud_upload_fields.argtypes = [vp, vp, i64, i64, i64, i64, i64]
         L.pct_cloud_append_aos.argtypes = [vp, vp, i64, i64]
         L.pct_cloud_build_grid.argtypes = [vp, C.c_float]
         L.pct_cloud_drop_grid.argtypes = [vp]
@@ -174,6 +175,11 @@ class Cloud:
     def set_input(self, points):
         a, stride = self._aos(points)
         _chk(lib().pct_cloud_upload_aos(self._h, _ptr(a), len(a), stride))
+
+    def set_input_pointcloud2(self, data: bytes, n: int, point_step: int, off_x: int, off_y: int, off_z: int):
+        """sensor_msgs/PointCloud2 payload: `data` = msg.data, offsets = msg.fields[*].offset"""
+        buf = np.frombuffer(data, np.uint8)
+        _chk(lib().pct_cloud_upload_fields(self._h, _ptr(buf), int(n), int(point_step), int(off_x), int(off_y), int(off_z)))
 
     def set_input_device(self, x_ptr: int, y_ptr: int, z_ptr: int, n: int):
         _chk(lib().pct_cloud_upload_soa_dev(self._h, x_ptr, y_ptr, z_ptr, int(n)))

@@ -401,3 +401,17 @@ def test_skewed_query_batches(E, oracle):
         ig, dg = c.nn(q, E.ALGO_GRID)
         assert np.array_equal(dg, bd) and np.array_equal(ig.astype(np.int64), bi.astype(np.int64))
     c.close()
+
+
+def test_pointcloud2_payload(E, oracle):
+    """rcvPointCloudCallBack's input: a PointCloud2 byte blob with an intensity field in front, z before y, 20-byte records"""
+    pts = synth.uniform_points(120, 3000, 0, 20)
+    rec = np.zeros(len(pts), dtype=[("intensity", "<f4"), ("x", "<f4"), ("z", "<f4"), ("y", "<f4"), ("ring", "<u4")])
+    rec["x"], rec["y"], rec["z"], rec["intensity"] = pts[:, 0], pts[:, 1], pts[:, 2], 7.0
+    c = E.Cloud(len(pts))
+    c.set_input_pointcloud2(rec.tobytes(), len(pts), rec.itemsize, 4, 12, 8)
+    q = synth.uniform_points(121, 100, 0, 20)
+    bi, bd = oracle.brute_nearest(pts, q)
+    i1, d1 = c.nn(q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    c.close()
