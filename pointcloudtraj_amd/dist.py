@@ -50,8 +50,13 @@ def merge_nearest(d2: torch.Tensor, idx: torch.Tensor, group=None) -> tuple[torc
 def _merge_nearest(d2, idx, group):
     best = d2.clone()
     dist.all_reduce(best, op=dist.ReduceOp.MIN, group=group)
-    cand = torch.where((d2 == best) & torch.isfinite(d2), idx, torch.full_like(idx, _I64_MAX))
+    # second message: 4 bytes per query while global indices fit int32 (NO_INDEX maps to INT32_MAX), else 8
+    narrow = idx.dtype == torch.int32
+    none = torch.iinfo(idx.dtype).max
+    cand = torch.where((d2 == best) & torch.isfinite(d2), idx, torch.full_like(idx, none))
     dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=group)
+    if narrow:
+        cand = torch.where(cand == none, torch.full_like(cand, -1), cand).to(torch.int64) & 0xFFFFFFFF
     return best, cand
 
 
@@ -115,6 +120,10 @@ class ShardedCloud:
         Q = q.shape[0]
         s = torch.cuda.current_stream().cuda_stream
         self.cloud.nn_device(q.data_ptr(), Q, self._idx32.data_ptr(), self._d2.data_ptr(), s, algo)
+        if self.world > 1 and self.n_total < 2 ** 31 - 1:
+            # indices < 2^31 are exchanged as int32 (the u32 bit pattern is non-negative; NO_INDEX -> INT32_MAX)
+            i32 = self._idx32[:Q]
+            return self._d2[:Q], torch.where(i32 < 0, torch.full_like(i32, torch.iinfo(torch.int32).max), i32)
         # u32 -> int64 (NO_INDEX stays recognisable through d2 == +inf)
         idx = self._idx32[:Q].to(torch.int64) & 0xFFFFFFFF
         return self._d2[:Q], idx

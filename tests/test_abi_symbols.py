@@ -64,3 +64,16 @@ def test_kdtree_create_fails_loudly_without_gpu(built, capfd):
         pytest.skip("a GPU is present")
     assert K.lib().kd_create(3) is None
     assert "no host fallback" in capfd.readouterr().err
+
+
+def test_corridor_exports_every_declared_symbol(built):
+    import ctypes as C2
+    from pointcloudtraj_amd import engine as E
+    names = declared("pct_corridor.h", "pct_corridor_")
+    assert len(names) >= 14
+    E._preload_hip_runtime()
+    C2.CDLL(built.ENGINE_SO, mode=C2.RTLD_GLOBAL)
+    C2.CDLL(built.KDTREE_SO, mode=C2.RTLD_GLOBAL)
+    L = C2.CDLL(built.CORRIDOR_SO)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing

@@ -52,6 +52,10 @@ def _worker(rank, world, port, n_total, case, out_dir):
         gd = torch.full((len(q),), float("inf"), dtype=torch.float64)
         cnt = torch.zeros(len(q), dtype=torch.int64)
     d2, idx = merge_nearest(gd, gi)
+    # the int32 exchange form used when all global indices fit 31 bits
+    gi32 = torch.where(torch.isfinite(gd), gi, torch.full_like(gi, 2 ** 31 - 1)).to(torch.int32)
+    d2b, idxb = merge_nearest(gd, gi32)
+    assert torch.equal(d2b, d2) and torch.equal(idxb, idx)
     total = merge_counts(cnt)
     if rank == 0:
         wi, wd = O.brute_nearest(pts, q)
