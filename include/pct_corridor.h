@@ -22,6 +22,9 @@ const char *pct_corridor_last_error(void);
 
 int pct_corridor_set_param(pct_corridor *c, double safety_margin, double search_margin, double max_radius, double sample_range);
 int pct_corridor_reset(pct_corridor *c);
+/* samples evaluated per GPU round trip in Expansion/Refine: 1 = one by one (the reference's loop); K > 1 = speculative batches
+ * that are replayed in order and give the identical corridor */
+int pct_corridor_set_speculation(pct_corridor *c, int k);
 int pct_corridor_set_input(pct_corridor *c, const void *points, int64_t n, int64_t stride_bytes, int build_index);
 int pct_corridor_set_pt(pct_corridor *c, const double start[3], const double end[3], double xl, double xh, double yl, double yh,
                         double zl, double zh, double local_range, int max_iter, double sample_portion, double goal_portion);
@@ -35,6 +38,7 @@ int pct_corridor_check_traj_pt_col(pct_corridor *c, const double p[3], int *coll
  * No path: the reference's placeholder, a 3x3 identity and three zero radii. */
 int pct_corridor_get_path(pct_corridor *c, double *path, double *radius, int64_t cap, int64_t *n_out);
 int pct_corridor_status(pct_corridor *c, int *path_exists, int *global_navi, int64_t *n_nodes, uint64_t *inflation_queries);
+int pct_corridor_speculation_stats(pct_corridor *c, uint64_t *replayed_from_batch, uint64_t *fell_back);
 
 #ifdef __cplusplus
 }

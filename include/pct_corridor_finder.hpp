@@ -11,6 +11,9 @@
 //     replaced by iteration counts so that a run is deterministic and comparable;
 //   * Eigen is replaced by a 3-double struct; std::default_random_engine / uniform_real_distribution by an own
 //     minstd_rand0 + generate_canonical<double,53> (what libstdc++ does), so results do not depend on the host library.
+//   * setSpeculation(K): the sampling loop may run K samples ahead on the GPU (three batched launches per K samples)
+//     and replay them in order on the host, falling back to the one-by-one path whenever an earlier sample of the batch
+//     changed what a later one would have seen -- the accepted nodes, and so the corridor, are identical to K = 1.
 // Numeric types follow data_type.h:12-51 exactly (Node::radius, g, f, rel_dis are float; coordinates double).
 #pragma once
 #include <algorithm>
@@ -20,6 +23,7 @@
 #include <vector>
 
 #include "kdtree/kdtree.h"
+#include "kdtree/kdtree_ext.h"
 #include "pct_obstacle_map.hpp"
 
 namespace pct {
@@ -66,6 +70,8 @@ public:
         return ret;
     }
     double uniform(double a, double b) { return canonical() * (b - a) + a; }
+    uint32_t state() const { return x_; }
+    void setState(uint32_t s) { x_ = s; }
 private:
     uint32_t x_;
 };
@@ -135,6 +141,10 @@ public:
     bool getGlobalNaviStatus() const { return global_navi_status; }
     ObstacleMap &obstacleMap() { return map_; }
     uint64_t inflationQueries() const { return n_inflate_; }
+    // samples evaluated per GPU round trip in Expansion/Refine (1 = the reference's one-by-one loop)
+    void setSpeculation(int k) { spec_k_ = std::max(1, std::min(k, 256)); }
+    uint64_t speculativeHits() const { return n_spec_hit_; }
+    uint64_t speculativeFallbacks() const { return n_spec_miss_; }
 
     // :226-270
     void resetRoot(const Vec3 &target_coord)
@@ -171,14 +181,14 @@ public:
         recordNode(root_node);
         insertKd(root_node);
         const int64_t limit = std::min<int64_t>(iterations, max_samples);
-        for (int64_t it = 0; it < limit; it++) growOnce(false);
+        growMany(limit, false);
         removeInvalid();
         tracePath();
     }
     // :765-815
     void SafeRegionRefine(int64_t iterations)
     {
-        for (int64_t it = 0; it < iterations; it++) growOnce(true);
+        growMany(iterations, true);
         removeInvalid();
         tracePath();
     }
@@ -301,6 +311,7 @@ private:
             if (inform_status) for (auto p : NodeList) p->best = false;
             for (NodePtr p = update_end_node; p != nullptr; p = p->preNode_ptr) p->best = true;
             best_end_ptr = update_end_node;
+            sample_epoch_++;          // the sampling ellipsoid changed
         }
     }
     Vec3 genSample()                                                     // :333-383
@@ -336,16 +347,7 @@ private:
     }
     NodePtr genNewNode(const Vec3 &pt_sample, NodePtr nearest)           // :385-410
     {
-        const double dis = getDis(nearest->coord, pt_sample);
-        Vec3 center;
-        if (dis > nearest->radius) {
-            const double steer_dis = nearest->radius / dis;
-            center.x = nearest->coord.x + (pt_sample.x - nearest->coord.x) * steer_dis;
-            center.y = nearest->coord.y + (pt_sample.y - nearest->coord.y) * steer_dis;
-            center.z = nearest->coord.z + (pt_sample.z - nearest->coord.z) * steer_dis;
-        } else {
-            center = pt_sample;
-        }
+        const Vec3 center = steer(pt_sample, nearest);
         const double radius_ = radiusSearch(center);
         const double h_dis_ = getDis(center, end_pt);
         return new CorridorNode(center, (float)radius_, (float)kInf, (float)h_dis_);
@@ -384,17 +386,22 @@ private:
     void recordNode(NodePtr n) { NodeList.push_back(n); }                                       // :569-573
 
     // one iteration of the Expansion (:719-756) / Refine (:772-808) loop body
-    void growOnce(bool refine)
+    void growOnce(bool refine) { growWithSample(genSample(), refine); }
+    void growWithSample(const Vec3 &pt_sample, bool refine)
     {
-        const Vec3 pt_sample = genSample();
         NodePtr nearest = findNearstVertex(pt_sample);
         if (nearest == nullptr || !nearest->valid) return;
         NodePtr fresh = genNewNode(pt_sample, nearest);
-        if (fresh->coord.z < z_l || fresh->radius < safety_margin_) { discarded_.push_back(fresh); return; }
-        treeRewire(fresh, nearest);
+        finishGrow(fresh, nearest, refine, nullptr);
+    }
+    // everything after genNewNode; presults != nullptr = the neighbourhood set was prepared by the caller
+    void finishGrow(NodePtr fresh, NodePtr nearest, bool refine, kdres *presults)
+    {
+        if (fresh->coord.z < z_l || fresh->radius < safety_margin_) { if (presults) kd_res_free(presults); discarded_.push_back(fresh); return; }
+        treeRewire(fresh, nearest, presults);
         if (!fresh->valid) { discarded_.push_back(fresh); return; }
         if (checkEnd(fresh)) {
-            if (!inform_status) best_end_ptr = fresh;
+            if (!inform_status) { best_end_ptr = fresh; sample_epoch_++; }      // genSample switches to the ellipsoid from now on
             EndList.push_back(fresh);
             if (refine) updateHeuristicRegion(fresh);
             inform_status = true;
@@ -403,6 +410,111 @@ private:
         recordNode(fresh);
         treePrune(fresh);
         if ((int)invalidSet.size() >= cach_size) removeInvalid();
+    }
+
+    static double kdDist2(const Vec3 &node_coord, const float q[3])      // the kd tree sees float-narrowed node positions and queries
+    {
+        const double dx = (double)(float)node_coord.x - (double)q[0], dy = (double)(float)node_coord.y - (double)q[1],
+                     dz = (double)(float)node_coord.z - (double)q[2];
+        double s = dx * dx;
+        s = s + dy * dy;
+        s = s + dz * dz;
+        return s;
+    }
+
+    void growMany(int64_t iterations, bool refine)
+    {
+        int64_t done = 0;
+        while (done < iterations) {
+            if (spec_k_ <= 1) { growOnce(refine); done++; continue; }
+            done += growBatch((int)std::min<int64_t>(spec_k_, iterations - done), refine);
+        }
+    }
+
+    // Speculative batch: evaluate K samples against a snapshot of the tree with three batched GPU calls, then replay them
+    // in order.  A sample is replayed from the precomputed answers only if nothing an earlier sample of the batch did could
+    // have changed them; otherwise it takes the one-by-one path, and if the sampling distribution or the kd tree itself
+    // changed (path found / improved, removeInvalid rebuilt the tree) the rest of the batch is discarded and the generator
+    // is rewound, so the sequence of samples is exactly the sequential one.  Returns the number of samples consumed.
+    int growBatch(int K, bool refine)
+    {
+        const uint64_t epoch0 = sample_epoch_, kd_epoch0 = kd_epoch_;
+        const int32_t n0 = kdx_size(kdTree_);
+        std::vector<Vec3> sample((size_t)K);
+        std::vector<uint32_t> rng_before((size_t)K + 1);
+        std::vector<float> posf((size_t)3 * K);
+        for (int i = 0; i < K; i++) {
+            rng_before[i] = eng_.state();
+            sample[i] = genSample();
+            posf[3 * i] = (float)sample[i].x; posf[3 * i + 1] = (float)sample[i].y; posf[3 * i + 2] = (float)sample[i].z;
+        }
+        rng_before[K] = eng_.state();
+        // stage A: nearest tree node of every sample
+        std::vector<int32_t> near_idx((size_t)K, -1);
+        kdx_nearestf_batch(kdTree_, posf.data(), K, near_idx.data());
+        // stage B: steer + inflate the candidate centres
+        std::vector<Vec3> center((size_t)K);
+        std::vector<double> cflat((size_t)3 * K), radius((size_t)K, 0.0);
+        for (int i = 0; i < K; i++) {
+            NodePtr nearest = near_idx[i] >= 0 ? (NodePtr)kdx_node_data(kdTree_, near_idx[i]) : nullptr;
+            center[i] = nearest ? steer(sample[i], nearest) : sample[i];
+            cflat[3 * i] = center[i].x; cflat[3 * i + 1] = center[i].y; cflat[3 * i + 2] = center[i].z;
+        }
+        map_.checkRadiusBatch(cflat.data(), K, radius.data());
+        // stage C: neighbourhood candidates for treeRewire (range = 2 * float radius, centre narrowed to float)
+        std::vector<float> cposf((size_t)3 * K), range((size_t)K);
+        for (int i = 0; i < K; i++) {
+            cposf[3 * i] = (float)center[i].x; cposf[3 * i + 1] = (float)center[i].y; cposf[3 * i + 2] = (float)center[i].z;
+            range[i] = std::max((float)radius[i], 0.0f) * 2.0f;
+        }
+        const int cap = 256;
+        std::vector<uint32_t> ids((size_t)K * cap);
+        std::vector<int32_t> counts((size_t)K, -1);
+        kdx_range_candidates_batch(kdTree_, cposf.data(), range.data(), K, ids.data(), cap, counts.data());
+
+        // replay, in order
+        for (int i = 0; i < K; i++) {
+            if (sample_epoch_ != epoch0 || kd_epoch_ != kd_epoch0) {      // what sample i would be, or the tree it would see, changed
+                eng_.setState(rng_before[i]);
+                return i;
+            }
+            // exact nearest = snapshot winner unless a node added during this batch is strictly closer
+            int32_t best = near_idx[i];
+            if (best < 0) { growWithSample(sample[i], refine); n_spec_miss_++; continue; }
+            const float *qf = &posf[3 * i];
+            double best_d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, best))->coord, qf);
+            const int32_t n_now = kdx_size(kdTree_);
+            for (int32_t j = n0; j < n_now; j++) {
+                const double d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, j))->coord, qf);
+                if (d2 < best_d2) { best_d2 = d2; best = j; }
+            }
+            if (best != near_idx[i]) { growWithSample(sample[i], refine); n_spec_miss_++; continue; }   // centre differs: one-by-one
+            NodePtr nearest = (NodePtr)kdx_node_data(kdTree_, best);
+            if (!nearest->valid) continue;                                                               // as the reference: skip the sample
+            n_inflate_++;
+            n_spec_hit_++;
+            NodePtr fresh = new CorridorNode(center[i], (float)radius[i], (float)kInf, (float)getDis(center[i], end_pt));
+            kdres *pre = nullptr;
+            if (!(fresh->coord.z < z_l || fresh->radius < safety_margin_)) {
+                const float r = fresh->radius * 2.0f;
+                pre = counts[i] >= 0 ? kdx_range_from_candidates(kdTree_, &cposf[3 * i], r, &ids[(size_t)i * cap], counts[i], n0)
+                                     : kd_nearest_rangef(kdTree_, &cposf[3 * i], r);
+            }
+            finishGrow(fresh, nearest, refine, pre);
+        }
+        return K;
+    }
+
+    Vec3 steer(const Vec3 &pt_sample, NodePtr nearest) const             // the first half of genNewNode (:387-404)
+    {
+        const double dis = getDis(nearest->coord, pt_sample);
+        if (dis > nearest->radius) {
+            const double steer_dis = nearest->radius / dis;
+            return Vec3(nearest->coord.x + (pt_sample.x - nearest->coord.x) * steer_dis,
+                        nearest->coord.y + (pt_sample.y - nearest->coord.y) * steer_dis,
+                        nearest->coord.z + (pt_sample.z - nearest->coord.z) * steer_dis);
+        }
+        return pt_sample;
     }
 
     void clearBranchW(NodePtr node)                                                             // :135-149
@@ -433,6 +545,7 @@ private:
     void removeInvalid()                                                                        // :170-231
     {
         std::vector<NodePtr> keep, ends;
+        kd_epoch_++;                  // node numbers of the kd tree change
         kd_clear(kdTree_);
         for (auto n : NodeList)
             if (n->valid) {
@@ -457,11 +570,13 @@ private:
         invalidSet.clear();
         for (auto n : deleteList) delete n;
     }
-    void treeRewire(NodePtr newPtr, NodePtr nearestPtr)                                         // :457-567
+    void treeRewire(NodePtr newPtr, NodePtr nearestPtr, kdres *presults = nullptr)              // :457-567
     {
-        const float range = newPtr->radius * 2.0f;
-        float pos[3] = { (float)newPtr->coord.x, (float)newPtr->coord.y, (float)newPtr->coord.z };
-        kdres *presults = kd_nearest_rangef(kdTree_, pos, range);
+        if (!presults) {
+            const float range = newPtr->radius * 2.0f;
+            float pos[3] = { (float)newPtr->coord.x, (float)newPtr->coord.y, (float)newPtr->coord.z };
+            presults = kd_nearest_rangef(kdTree_, pos, range);
+        }
         std::vector<NodePtr> nearPtrList;
         bool isInvalid = false;
         while (!kd_res_end(presults)) {
@@ -619,7 +734,8 @@ private:
     std::vector<Vec3> Path;
     std::vector<double> Radius;
     MinStdRand0 eng_;
-    uint64_t n_inflate_ = 0;
+    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0;
+    int spec_k_ = 32;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
 };
 
 }  // namespace pct

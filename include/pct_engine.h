@@ -108,6 +108,10 @@ int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const fl
  * ascending index order; returns the count through *n_out (may exceed cap; only cap written). */
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
 int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+/* K range queries against a SMALL cloud (<= 65536 points) in one launch.  ids_out[k*cap_per_query + j] in arrival order;
+ * counts_out[k] >= 0: number of hits, all stored; < 0: -(number of hits), list truncated -- ask that query alone. */
+int pct_radius_indices_batch_q64(pct_cloud *c, const double *q, const double *r, int64_t K, uint32_t *ids_out, int64_t cap_per_query,
+                                 int64_t *counts_out);
 
 typedef struct pct_inflate_params {
     double start[3];        /* start_pt */

@@ -33,7 +33,8 @@ def _stale(target: str, sources: list[str]) -> bool:
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIB, exist_ok=True)
-    hdrs = [os.path.join(ROOT, "include", "pct_engine.h"), os.path.join(ROOT, "include", "kdtree", "kdtree.h")]
+    hdrs = [os.path.join(ROOT, "include", "pct_engine.h"), os.path.join(ROOT, "include", "kdtree", "kdtree.h"),
+            os.path.join(ROOT, "include", "kdtree", "kdtree_ext.h")]
     eng_src = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "kernels.hpp")]
     if force or _stale(ENGINE_SO, eng_src + hdrs):
         cmd = [HIPCC, *COMMON, "-o", ENGINE_SO, eng_src[0]]
@@ -43,7 +44,7 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     kd_src = [os.path.join(CSRC, "kdtree_gpu.cpp")]
     if os.path.exists(kd_src[0]) and (force or _stale(KDTREE_SO, kd_src + hdrs + [ENGINE_SO])):
         # host-only C++ (no device code): it reaches the GPU through libpct_engine.so's C ABI
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"),
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                "-o", KDTREE_SO, kd_src[0], "-L" + LIB, "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-soname,libkdtree.so"]
         if verbose:
             print(" ".join(cmd))

@@ -28,6 +28,8 @@ def lib():
         L.pct_corridor_destroy.argtypes = [vp]
         L.pct_corridor_set_param.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.pct_corridor_reset.argtypes = [vp]
+        L.pct_corridor_set_speculation.argtypes = [vp, C.c_int]
+        L.pct_corridor_speculation_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_corridor_set_input.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int]
         L.pct_corridor_set_pt.argtypes = [vp, d3, d3] + [C.c_double] * 7 + [C.c_int, C.c_double, C.c_double]
         L.pct_corridor_set_start_pt.argtypes = [vp, d3, d3]
@@ -68,6 +70,14 @@ class SafeRegionRrtStar:
 
     def reset(self):
         self._chk(self.L.pct_corridor_reset(self.h))
+
+    def setSpeculation(self, k: int):
+        self._chk(self.L.pct_corridor_set_speculation(self.h, int(k)))
+
+    def speculationStats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.pct_corridor_speculation_stats(self.h, C.byref(a), C.byref(b)))
+        return dict(replayed_from_batch=a.value, fell_back=b.value)
 
     def setInput(self, points, build_index=True):
         a = np.ascontiguousarray(points, np.float32)

@@ -48,6 +48,11 @@ int pct_corridor_set_param(pct_corridor *c, double safety_margin, double search_
     return guarded([&] { c->impl->setParam(safety_margin, search_margin, max_radius, sample_range); });
 }
 int pct_corridor_reset(pct_corridor *c) { return guarded([&] { c->impl->reset(); }); }
+int pct_corridor_set_speculation(pct_corridor *c, int k) { return guarded([&] { c->impl->setSpeculation(k); }); }
+int pct_corridor_speculation_stats(pct_corridor *c, uint64_t *hit, uint64_t *miss)
+{
+    return guarded([&] { if (hit) *hit = c->impl->speculativeHits(); if (miss) *miss = c->impl->speculativeFallbacks(); });
+}
 int pct_corridor_set_input(pct_corridor *c, const void *points, int64_t n, int64_t stride_bytes, int build_index)
 {
     return guarded([&] { c->impl->setInput(points, n, stride_bytes, build_index != 0); });

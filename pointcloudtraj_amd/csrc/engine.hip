@@ -100,7 +100,7 @@ struct pct_cloud {
     float *hx = nullptr, *hy = nullptr, *hz = nullptr;
     // express path: host-mapped result / argument / id buffers
     ExpressOut *h_xout = nullptr, *d_xout = nullptr;
-    double *h_xin = nullptr, *d_xin = nullptr;
+    double *h_xin = nullptr, *d_xin = nullptr, *h_xr = nullptr, *d_xr = nullptr;
     uint32_t *h_xids = nullptr, *d_xids = nullptr;
     unsigned char *d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -540,6 +540,7 @@ static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out
     if (!s) s = dev_alloc(&c->d_work, kWorkSlots);
     if (!s) s = mapped_alloc(&c->h_xout, &c->d_xout, kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xin, &c->d_xin, 3 * kExpressMaxQ);
+    if (!s) s = mapped_alloc(&c->h_xr, &c->d_xr, kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xids, &c->d_xids, kExpressIdsCap);
     if (s) {
         pct_cloud_destroy(c);
@@ -574,6 +575,7 @@ int pct_cloud_destroy(pct_cloud *c)
     }
     if (c->h_xout) (void)hipHostFree(c->h_xout);
     if (c->h_xin) (void)hipHostFree(c->h_xin);
+    if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
@@ -888,6 +890,14 @@ int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, do
         for (int64_t i = 0; i < Q; i++) { idx[i] = PCT_NO_INDEX; d2[i] = INFINITY; }
         return fail(PCT_ERR_EMPTY, "nearest-neighbour query against an empty cloud");
     }
+    if (Q > 1 && Q <= kExpressMaxQ && c->count <= kSmallNNMax) {   // express batch: a block per query, everything in mapped memory
+        std::memcpy(c->h_xin, q, sizeof(double) * 3 * Q);
+        nn_small_batch_kernel<<<(int)Q, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_xin, (uint32_t)c->index_base, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
+        return PCT_OK;
+    }
     if (Q == 1 && c->count <= kSmallNNMax) {   // express: one one-block launch, query by value, result in mapped memory
         nn_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], (uint32_t)c->index_base, c->d_xout);
         HIPCHK(hipGetLastError());
@@ -975,6 +985,32 @@ int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *
     if (e != hipSuccess) return fail(PCT_ERR_HIP, "radius_indices failed: %s", hipGetErrorString(e));
     std::sort(idx_out, idx_out + got);   // ascending index order (the kernel appends in arrival order)
     *n_out = total;
+    return PCT_OK;
+}
+
+// K range queries against a small cloud in one launch: ids_out[k * cap_per_query + j] (arrival order, not sorted),
+// counts_out[k] = number of hits of query k (may exceed cap_per_query: then only the first cap_per_query are stored).
+int pct_radius_indices_batch_q64(pct_cloud *c, const double *q, const double *r, int64_t K, uint32_t *ids_out, int64_t cap_per_query,
+                                 int64_t *counts_out)
+{
+    if (!c || K < 0 || (K > 0 && (!q || !r || !ids_out || !counts_out)) || cap_per_query <= 0) return fail(PCT_ERR_INVALID, "bad radius_indices_batch arguments");
+    if (K == 0) return PCT_OK;
+    if (K > kExpressMaxQ || c->count > 4 * kSmallNNMax) return fail(PCT_ERR_INVALID, "batched range queries serve small clouds (<= 65536 points) and K <= 1024");
+    for (int64_t k = 0; k < K; k++) counts_out[k] = 0;
+    if (c->count == 0) return PCT_OK;
+    const uint32_t cap = (uint32_t)std::min<int64_t>(cap_per_query, kExpressIdsCap / K);
+    std::memcpy(c->h_xin, q, sizeof(double) * 3 * K);
+    std::memcpy(c->h_xr, r, sizeof(double) * K);
+    radius_small_batch_kernel<<<(int)K, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_xin, c->d_xr, (uint32_t)c->index_base,
+                                                            c->d_xids, cap, c->d_xout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int64_t k = 0; k < K; k++) {
+        counts_out[k] = c->h_xout[k].count;
+        const int64_t got = std::min<int64_t>(counts_out[k], cap);
+        std::copy(c->h_xids + k * cap, c->h_xids + k * cap + got, ids_out + k * cap_per_query);
+        if (counts_out[k] > cap) counts_out[k] = -counts_out[k];      // negative = truncated: the caller must re-ask that query alone
+    }
     return PCT_OK;
 }
 

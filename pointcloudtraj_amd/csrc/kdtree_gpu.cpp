@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "kdtree/kdtree.h"
+#include "kdtree/kdtree_ext.h"
 #include "pct_engine.h"
 
 namespace {
@@ -120,6 +121,29 @@ bool walk_path(const kdtree *t, int32_t n, const double *q, double range, std::v
     }
     std::reverse(path.begin(), path.end());
     return true;
+}
+
+// replay the reference walk's pruning (kdtree.c:283) and visit order over a list of in-range nodes
+kdres *build_range_result(kdtree *t, const double *q, double range, const uint32_t *hits, int64_t nh)
+{
+    kdres *r = new (std::nothrow) kdres();
+    if (!r) return nullptr;
+    r->tree = t;
+    struct Hit { int32_t id; std::vector<uint8_t> path; };
+    std::vector<Hit> kept;
+    kept.reserve((size_t)nh);
+    std::vector<uint8_t> path;
+    for (int64_t i = 0; i < nh; i++)
+        if (walk_path(t, (int32_t)hits[i], q, range, path)) kept.push_back(Hit{ (int32_t)hits[i], path });
+    // pre-order, nearer child before farther child: an ancestor's path is a proper prefix of its
+    // descendants' and sorts first; siblings sort by their first differing step
+    std::sort(kept.begin(), kept.end(), [](const Hit &a, const Hit &b) {
+        return std::lexicographical_compare(a.path.begin(), a.path.end(), b.path.begin(), b.path.end());
+    });
+    r->items.reserve(kept.size());
+    for (size_t i = kept.size(); i-- > 0;) r->items.push_back(kept[i].id);   // head insertion => reverse visit order
+    r->size = (int)r->items.size();
+    return r;
 }
 
 }  // namespace
@@ -254,22 +278,9 @@ struct kdres *kd_nearest_range(struct kdtree *t, const double *q, double range)
     std::vector<uint32_t> hits((size_t)n);
     int64_t nh = 0;
     if (pct_radius_indices_q64(t->cloud, q, range, hits.data(), n, &nh) != PCT_OK) { complain("kd_nearest_range"); delete r; return nullptr; }
-    // replay the reference walk's pruning and visit order over the device's hit list
-    struct Hit { int32_t id; std::vector<uint8_t> path; };
-    std::vector<Hit> kept;
-    kept.reserve((size_t)nh);
-    std::vector<uint8_t> path;
-    for (int64_t i = 0; i < nh; i++)
-        if (walk_path(t, (int32_t)hits[i], q, range, path)) kept.push_back(Hit{ (int32_t)hits[i], path });
-    // pre-order, nearer child before farther child: an ancestor's path is a proper prefix of its
-    // descendants' and sorts first; siblings sort by their first differing step
-    std::sort(kept.begin(), kept.end(), [](const Hit &a, const Hit &b) {
-        return std::lexicographical_compare(a.path.begin(), a.path.end(), b.path.begin(), b.path.end());
-    });
-    r->items.reserve(kept.size());
-    for (size_t i = kept.size(); i-- > 0;) r->items.push_back(kept[i].id);   // head insertion => reverse visit order
-    r->size = (int)r->items.size();
-    return r;
+    kdres *out = build_range_result(t, q, range, hits.data(), nh);
+    delete r;
+    return out;
 }
 struct kdres *kd_nearest_rangef(struct kdtree *t, const float *q, float range)
 {
@@ -335,5 +346,63 @@ void *kd_res_item3f(struct kdres *r, float *x, float *y, float *z)
     return nullptr;
 }
 void *kd_res_item_data(struct kdres *r) { return kd_res_item(r, nullptr); }
+
+// ---- batch extensions (include/kdtree/kdtree_ext.h) ---------------------------------------------------------
+int kdx_size(struct kdtree *t) { return t ? (int)t->count() : 0; }
+void *kdx_node_data(struct kdtree *t, int32_t node) { return (t && node >= 0 && node < t->count()) ? t->data[node] : nullptr; }
+int kdx_node_pos(struct kdtree *t, int32_t node, double pos[3])
+{
+    if (!t || node < 0 || node >= t->count()) return -1;
+    std::memcpy(pos, &t->pos[3 * (size_t)node], 3 * sizeof(double));
+    return 0;
+}
+
+int kdx_nearestf_batch(struct kdtree *t, const float *pos, int k, int32_t *node_out)
+{
+    if (!t || k < 0 || (k > 0 && (!pos || !node_out))) return -1;
+    if (t->count() == 0) { for (int i = 0; i < k; i++) node_out[i] = -1; return 0; }
+    if (sync_device(t)) return -1;
+    std::vector<double> q((size_t)3 * k), d2((size_t)k);
+    std::vector<uint32_t> idx((size_t)k);
+    for (int i = 0; i < 3 * k; i++) q[i] = pos[i];
+    if (pct_nn_batch_q64(t->cloud, q.data(), k, idx.data(), d2.data()) != PCT_OK) { complain("kdx_nearestf_batch"); return -1; }
+    for (int i = 0; i < k; i++) node_out[i] = (int32_t)idx[i];
+    return 0;
+}
+
+int kdx_range_candidates_batch(struct kdtree *t, const float *pos, const float *range, int k, uint32_t *ids, int cap_per_query,
+                               int32_t *counts)
+{
+    if (!t || k < 0 || (k > 0 && (!pos || !range || !ids || !counts)) || cap_per_query <= 0) return -1;
+    for (int i = 0; i < k; i++) counts[i] = 0;
+    if (t->count() == 0 || k == 0) return 0;
+    if (sync_device(t)) return -1;
+    std::vector<double> q((size_t)3 * k), r((size_t)k);
+    std::vector<int64_t> cnt((size_t)k);
+    for (int i = 0; i < 3 * k; i++) q[i] = pos[i];
+    for (int i = 0; i < k; i++) r[i] = range[i];
+    if (pct_radius_indices_batch_q64(t->cloud, q.data(), r.data(), k, ids, cap_per_query, cnt.data()) != PCT_OK) {
+        for (int i = 0; i < k; i++) counts[i] = -1;          // e.g. a tree too large for the batched kernel: ask one by one
+        return 0;
+    }
+    for (int i = 0; i < k; i++) counts[i] = (int32_t)cnt[i];
+    return 0;
+}
+
+struct kdres *kdx_range_from_candidates(struct kdtree *t, const float *pos, float range, const uint32_t *ids, int n_ids, int32_t n_snapshot)
+{
+    const double q[3] = { pos[0], pos[1], pos[2] };
+    const double rng = range, r2 = rng * rng;
+    std::vector<uint32_t> hits(ids, ids + n_ids);
+    for (int64_t j = std::max<int32_t>(n_snapshot, 0); j < t->count(); j++) {      // nodes younger than the snapshot: host test, same arithmetic
+        const double *p = &t->pos[3 * (size_t)j];
+        const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        double d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        d2 = d2 + dz * dz;
+        if (d2 <= r2) hits.push_back((uint32_t)j);
+    }
+    return build_range_result(t, q, rng, hits.data(), (int64_t)hits.size());
+}
 
 }  // extern "C"

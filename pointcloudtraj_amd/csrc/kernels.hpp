@@ -1371,6 +1371,53 @@ __global__ __launch_bounds__(1024) void radius_small_kernel(const float *__restr
 // =====================================================================================
 // 5. Planner arithmetic around the NN: sphere inflation and the sampled Bezier check
 // =====================================================================================
+// batched forms for speculative RRT* expansion: one 256-thread block per query over a small cloud
+__global__ __launch_bounds__(256) void nn_small_batch_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, uint32_t n,
+                                                             const double *__restrict__ q, uint32_t index_base,
+                                                             ExpressOut *__restrict__ out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const double qx = q[3 * blockIdx.x], qy = q[3 * blockIdx.x + 1], qz = q[3 * blockIdx.x + 2];
+    double bd = __builtin_huge_val();
+    uint32_t bi = kNoIndex;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const double d2 = dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz);
+        if (d2 < bd) { bd = d2; bi = i; }
+    }
+    wave_argmin(bd, bi);
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = bd; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
+        out[blockIdx.x].d2 = bd;
+        out[blockIdx.x].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+    }
+}
+
+// ids[block * cap_per_query + k] = k-th hit (arrival order), out[block].count = number of hits (may exceed the cap)
+__global__ __launch_bounds__(256) void radius_small_batch_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                 const float *__restrict__ z, uint32_t n,
+                                                                 const double *__restrict__ q, const double *__restrict__ r,
+                                                                 uint32_t index_base, uint32_t *__restrict__ ids,
+                                                                 uint32_t cap_per_query, ExpressOut *__restrict__ out)
+{
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const double qx = q[3 * blockIdx.x], qy = q[3 * blockIdx.x + 1], qz = q[3 * blockIdx.x + 2];
+    const double r2 = r[blockIdx.x] * r[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz) <= r2) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            if (pos < cap_per_query) ids[(size_t)blockIdx.x * cap_per_query + pos] = i + index_base;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x].count = s_n;
+}
+
 struct InflateParams { double sx, sy, sz, sample_range, search_margin, max_radius; };
 
 // corridor_finder.cpp:113-126: early-out test in fp64 on the planner's Vector3d, then the

@@ -9,7 +9,13 @@ import corridor_scenario as S
 engine.init(0)
 c1 = S.sensed_cloud(12.0)
 p = S.PARAMS
-for name, mk in (("cpu oracle", lambda: O.PortCorridor()), ("gpu engine", lambda: corridor.SafeRegionRrtStar(80000))):
+def mk_gpu(k):
+    def f():
+        c = corridor.SafeRegionRrtStar(80000)
+        c.setSpeculation(k)
+        return c
+    return f
+for name, mk in (("cpu oracle", lambda: O.PortCorridor()), ("gpu engine K=1", mk_gpu(1)), ("gpu engine K=16", mk_gpu(16)), ("gpu engine K=64", mk_gpu(64)), ("gpu engine K=256", mk_gpu(256))):
     for rep in range(2):
         f = mk()
         t = [time.perf_counter()]
@@ -22,4 +28,5 @@ for name, mk in (("cpu oracle", lambda: O.PortCorridor()), ("gpu engine", lambda
         f.SafeRegionEvaluate(); t.append(time.perf_counter())
         f.SafeRegionRefine(200); t.append(time.perf_counter())
         d = np.diff(t) * 1e3
-        print(f"{name}: setInput {d[0]:.2f}  setPt {d[1]:.2f}  expansion(1500) {d[2]:.2f}  refine(400) {d[3]:.2f}  setInput2 {d[4]:.2f}  evaluate {d[5]:.2f}  refine(200) {d[6]:.2f} ms   status {f.status()}", flush=True)
+        extra = f.speculationStats() if hasattr(f, "speculationStats") else ""
+        print(f"{name}: {extra} setInput {d[0]:.2f}  setPt {d[1]:.2f}  expansion(1500) {d[2]:.2f}  refine(400) {d[3]:.2f}  setInput2 {d[4]:.2f}  evaluate {d[5]:.2f}  refine(200) {d[6]:.2f} ms   status {f.status()}", flush=True)

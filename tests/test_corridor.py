@@ -45,13 +45,20 @@ def test_oracle_corridor_c1(oracle):
 
 
 @pytest.mark.gpu
-def test_gpu_corridor_matches_oracle(oracle):
+@pytest.mark.parametrize("speculation", [1, 8, 64])
+def test_gpu_corridor_matches_oracle(oracle, speculation):
+    """speculation = samples per GPU round trip; every setting must give the one-by-one corridor"""
     from pointcloudtraj_amd import corridor, engine
     engine.init(0)
     cloud1 = sensed_cloud(12.0)
     for cloud2 in (None, sensed_cloud(16.0)):
         want = run_scenario(oracle.PortCorridor(), cloud1, cloud2, expand=600, refine=200)
-        got = run_scenario(corridor.SafeRegionRrtStar(80000), cloud1, cloud2, expand=600, refine=200)
+        finder = corridor.SafeRegionRrtStar(80000)
+        finder.setSpeculation(speculation)
+        got = run_scenario(finder, cloud1, cloud2, expand=600, refine=200)
+        if speculation > 1:
+            st = finder.speculationStats()
+            assert st["replayed_from_batch"] > 100, st
         for k, ((pw, rw, sw), (pg, rg, sg)) in enumerate(zip(want, got)):
             assert sw["path_exists"] == sg["path_exists"] and sw["nodes"] == sg["nodes"], f"phase {k}: {sw} vs {sg}"
             assert np.array_equal(pw, pg), f"phase {k}: corridor centres differ"
