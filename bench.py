@@ -298,6 +298,14 @@ def main():
 
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
+        # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
+        # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches of 32 samples
+        from pointcloudtraj_amd import corridor, scenarios
+        cloud1 = scenarios.sensed_cloud(12.0)
+        scenarios.timed_scenario(corridor.SafeRegionRrtStar(80000), cloud1)          # warm-up (first launches, allocations)
+        out["corridor_replan_probe"] = dict(scenarios.timed_scenario(corridor.SafeRegionRrtStar(80000), cloud1),
+                                            what="C1 corridor scenario: setInput + SafeRegionExpansion(1500) + Refine(400) + new frame + Evaluate + Refine(200)",
+                                            cloud_points=int(len(cloud1)))
 
     if a.cpu_queries > 0 and world == 1:
         ncpu = a.cpu_points or a.points
@@ -306,6 +314,14 @@ def main():
         if ncpu == a.points:     # same cloud: the GPU answers must equal the host kd-tree's (parity in the bench run itself)
             gi = idx[:len(cq)].cpu().numpy()
             out["cpu_baseline"]["gpu_matches_cpu_indices"] = bool(np.array_equal(gi, cpu_idx))
+        if "corridor_replan_probe" in out:   # the same corridor scenario on the CPU restatement (oracle/rrt_port.c + kd-tree port), one core
+            from oracle import oracle as O
+            from pointcloudtraj_amd import scenarios
+            cpu_cor = scenarios.timed_scenario(O.PortCorridor(), scenarios.sensed_cloud(12.0))
+            out["cpu_baseline"]["corridor_replan_ms"] = cpu_cor["total_ms"]
+            out["cpu_baseline"]["corridor_phases_ms"] = {k: v for k, v in cpu_cor.items() if k.endswith("_ms")}
+            out["cpu_baseline"]["corridor_same_path_as_gpu"] = bool(cpu_cor["status"] == out["corridor_replan_probe"]["status"]
+                                                                     and cpu_cor["path_len"] == out["corridor_replan_probe"]["path_len"])
     print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()

@@ -1,9 +1,11 @@
-"""Config C1 corridor scenario shared by the CPU and GPU corridor tests: the clean_demo map (seed 6), start
+"""Workload definitions shared by tests, probes and bench.py (no oracle, no GPU code).
+
+Config C1 corridor scenario: the clean_demo map (seed 6), start
 (-10,-10,2) -> goal (9,9,2), clean_demo.launch planner constants, fixed iteration counts instead of wall-clock
 limits, and a second, denser cloud for the lazy re-evaluation."""
 import numpy as np
 
-from pointcloudtraj_amd import synth
+from . import synth
 
 START, GOAL = (-10.0, -10.0, 2.0), (9.0, 9.0, 2.0)
 BOUNDS = (-15.0, 15.0, -15.0, 15.0, 0.0, 4.0)
@@ -45,4 +47,29 @@ def run_scenario(finder, cloud1, cloud2=None, expand=1500, refine=400):
     out.append((*finder.getPath(), finder.status()))
     finder.SafeRegionRefine(refine // 2)
     out.append((*finder.getPath(), finder.status()))
+    return out
+
+
+def timed_scenario(finder, cloud1, expand=1500, refine=400):
+    """run_scenario with wall-clock milliseconds per planner phase (bench.py / scripts/probe_corridor.py)"""
+    import time
+    p = PARAMS
+    t = [time.perf_counter()]
+    finder.setParam(p["safety_margin"], p["search_margin"], p["max_radius"], p["sensing_range"])
+    finder.setInput(cloud1); t.append(time.perf_counter())
+    finder.reset()
+    finder.setPt(START, GOAL, *BOUNDS, p["sensing_range"], p["max_samples"], p["sample_portion"], p["goal_portion"])
+    finder.SafeRegionExpansion(expand); t.append(time.perf_counter())
+    finder.SafeRegionRefine(refine); t.append(time.perf_counter())
+    path, _ = finder.getPath()
+    cloud2 = perturbed_cloud(cloud1, path)
+    t.append(time.perf_counter())
+    finder.setInput(cloud2); t.append(time.perf_counter())
+    finder.SafeRegionEvaluate(); t.append(time.perf_counter())
+    finder.SafeRegionRefine(refine // 2); t.append(time.perf_counter())
+    d = [1e3 * (b - a) for a, b in zip(t[:-1], t[1:])]
+    out = {"set_input_ms": d[0], "expansion_ms": d[1], "refine_ms": d[2], "set_input_2_ms": d[4], "evaluate_ms": d[5], "refine_2_ms": d[6]}
+    out["total_ms"] = sum(out.values())
+    out["status"] = finder.status()
+    out["path_len"] = len(finder.getPath()[0])
     return out

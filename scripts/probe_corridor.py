@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from pointcloudtraj_amd import corridor, engine
 from oracle import oracle as O
-import corridor_scenario as S
+from pointcloudtraj_amd import scenarios as S
 engine.init(0)
 c1 = S.sensed_cloud(12.0)
 p = S.PARAMS

@@ -3,7 +3,7 @@ finder against the oracle (two independent implementations, no shared code) for 
 import numpy as np
 import pytest
 
-from corridor_scenario import GOAL, START, run_scenario, sensed_cloud
+from pointcloudtraj_amd.scenarios import GOAL, START, run_scenario, sensed_cloud
 
 
 def check_corridor(path, radius, cloud, safety=0.6):
@@ -20,7 +20,7 @@ def check_corridor(path, radius, cloud, safety=0.6):
 
 
 def test_oracle_corridor_c1(oracle):
-    from corridor_scenario import perturbed_cloud
+    from pointcloudtraj_amd.scenarios import perturbed_cloud
     cloud1 = sensed_cloud(12.0)
     for cloud2 in (None, sensed_cloud(16.0)):       # a mild change (corridor survives, radii shrink) and a drastic one
         f = oracle.PortCorridor()
