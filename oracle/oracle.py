@@ -96,7 +96,10 @@ def ref_libs():
     if _ref is None:
         if not have_ref():
             raise FileNotFoundError("oracle/_ref is not built (needs /root/reference; run `make -C oracle`)")
-        R = C.CDLL(_REF)
+        # RTLD_DEEPBIND: the shim's kd_* calls must bind to the reference library it was linked against even when the
+        # product's libkdtree.so (same symbol names) is loaded in the same process
+        deep = getattr(os, "RTLD_DEEPBIND", 0)
+        R = C.CDLL(_REF, mode=C.RTLD_LOCAL | deep)
         R.kd_create.restype = C.c_void_p
         R.kd_create.argtypes = [C.c_int]
         R.kd_free.argtypes = [C.c_void_p]
@@ -113,7 +116,7 @@ def ref_libs():
         R.kd_res_item_data.restype = C.c_void_p
         R.kd_insert.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
         R.kd_data_destructor.argtypes = [C.c_void_p, C.c_void_p]
-        S = C.CDLL(_SHIM)
+        S = C.CDLL(_SHIM, mode=C.RTLD_LOCAL | deep)
         S.refshim_insertf_batch.restype = C.c_int64
         S.refshim_insertf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64, C.c_int64]
         S.refshim_nearestf_batch.argtypes = [C.c_void_p, _f32p, C.c_int64, _i32p, _f64p]

@@ -47,8 +47,7 @@ def test_kdtree_exports_every_reference_function(built):
     import ctypes as C2
     from pointcloudtraj_amd import engine as E
     E._preload_hip_runtime()
-    C2.CDLL(built.ENGINE_SO, mode=C2.RTLD_GLOBAL)
-    L = C2.CDLL(built.KDTREE_SO)
+    L = C2.CDLL(built.KDTREE_SO)          # libpct_engine.so comes in as its DT_NEEDED dependency (RUNPATH $ORIGIN), local scope
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     want = ["kd_create", "kd_free", "kd_clear", "kd_data_destructor", "kd_insert", "kd_insertf", "kd_insert3", "kd_insert3f",
@@ -72,8 +71,6 @@ def test_corridor_exports_every_declared_symbol(built):
     names = declared("pct_corridor.h", "pct_corridor_")
     assert len(names) >= 14
     E._preload_hip_runtime()
-    C2.CDLL(built.ENGINE_SO, mode=C2.RTLD_GLOBAL)
-    C2.CDLL(built.KDTREE_SO, mode=C2.RTLD_GLOBAL)
-    L = C2.CDLL(built.CORRIDOR_SO)
+    L = C2.CDLL(built.CORRIDOR_SO)        # pulls libkdtree.so and libpct_engine.so through DT_NEEDED, local scope
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
