@@ -547,6 +547,28 @@ __device__ __forceinline__ uint32_t cell_lin(const GridDesc &G, int cx, int cy, 
     return ((uint32_t)cz * (uint32_t)G.gy + (uint32_t)cy) * (uint32_t)G.gx + (uint32_t)cx;
 }
 
+// OPTIONAL coarser copies of the index (cell size x4 per level, same origin), used only by the block-per-query
+// express kernel: a query that finds nothing decisive in its 3x3x3 fine cells tries the 3x3x3 cells of each coarser
+// level before expanding shell by shell at the coarsest level.  n = 0: no pyramid (the default, see engine.hip).
+constexpr int kMaxCoarse = 3;
+struct CoarseLevels {
+    int n;
+    GridDesc G[kMaxCoarse];
+    const float4 *pts[kMaxCoarse];
+    const uint32_t *cell_start[kMaxCoarse];
+};
+
+__global__ __launch_bounds__(256) void count_empty_cells_kernel(const uint32_t *__restrict__ cell_start, uint32_t ncells,
+                                                                uint32_t *__restrict__ n_empty)
+{
+    uint32_t c = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncells; i += stride) c += cell_start[i + 1] == cell_start[i] ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, kWave);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(n_empty, c);
+}
+
 // per-block min/max -> partials[block][6]
 __global__ __launch_bounds__(256) void bbox_partial_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                            const float *__restrict__ z, uint32_t n,
@@ -873,6 +895,20 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nb
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// distance from q to the nearest face of the cube of cells [c-r, c+r]^3 that still has cells behind it
+// (+inf when the cube covers the whole grid), minus the slack that covers the fp32 cell assignment
+__device__ __forceinline__ double cube_bound(const GridDesc &G, int cx, int cy, int cz, int r, double qx, double qy, double qz)
+{
+    double bound = __builtin_huge_val();
+    if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
+    if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
+    if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
+    if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
+    if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
+    if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
+    return bound == __builtin_huge_val() ? bound : bound - G.hd * (1.0 / 256.0);
+}
+
 // Points [s, e) of the cell-sorted array against one query.  Four independent 16-byte loads are
 // issued before the first compare (the tail repeats the last point: a repeated (d2, index) never
 // changes the winner), so a short run costs one memory round trip instead of one per point.
@@ -1086,6 +1122,40 @@ __device__ __forceinline__ void coop_scan_exact(const float4 *__restrict__ pts, 
     }
 }
 
+// rows of the cube (full = true) or of the shell of Chebyshev radius r around cell (cx,cy,cz), shared by 8 lanes
+template <bool COUNT>
+__device__ __forceinline__ void coop_scan_cube_or_shell(const GridDesc &G, const float4 *__restrict__ pts,
+                                                        const uint32_t *__restrict__ cell_start, int cx, int cy, int cz, int r,
+                                                        bool full, uint32_t sub, double qx, double qy, double qz, double &bd,
+                                                        uint32_t &bi, uint32_t &npts, uint32_t &nruns)
+{
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
+    const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
+    for (int zz = z0; zz <= z1; zz++) {
+        const bool zface = (zz == cz - r) || (zz == cz + r);
+        for (int yy = y0; yy <= y1; yy++) {
+            const uint32_t row = cell_lin(G, 0, yy, zz);
+            if (full || zface || yy == cy - r || yy == cy + r) {
+                const uint32_t s = cell_start[row + x0], e = cell_start[row + x1 + 1];
+                if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+            } else {
+                if (cx - r >= 0) {
+                    const uint32_t s = cell_start[row + cx - r], e = cell_start[row + cx - r + 1];
+                    if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                    coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                }
+                if (cx + r <= G.gx - 1) {
+                    const uint32_t s = cell_start[row + cx + r], e = cell_start[row + cx + r + 1];
+                    if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
+                    coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
+                }
+            }
+        }
+    }
+}
+
 // The search itself, shared by the batch kernel and the low-latency inflation kernel: all 8 lanes of
 // a group call it with the same query and their own `sub`; every lane returns the same (bd, bi).
 template <bool COUNT>
@@ -1099,7 +1169,6 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
     const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
     bd = __builtin_huge_val();
     bi = kNoIndex;
-    const double slack = G.hd * (1.0 / 256.0);
     {   // ---- first cube: 3x3x3 cells = 9 x-runs ----
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
         // lane `sub` fetches row `sub`'s bounds, lane 0 also row 8
@@ -1188,44 +1257,12 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
         }
     }
     for (int r = 1;; r++) {
-        if (r > 1) {   // ---- shell r (rare): rows walked in the same order by the whole group ----
-            const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
-            const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
-            const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
-            for (int zz = z0; zz <= z1; zz++) {
-                const bool zface = (zz == cz - r) || (zz == cz + r);
-                for (int yy = y0; yy <= y1; yy++) {
-                    const uint32_t row = cell_lin(G, 0, yy, zz);
-                    if (zface || yy == cy - r || yy == cy + r) {
-                        const uint32_t s = cell_start[row + x0], e = cell_start[row + x1 + 1];
-                        if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                        coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                    } else {
-                        if (cx - r >= 0) {
-                            const uint32_t s = cell_start[row + cx - r], e = cell_start[row + cx - r + 1];
-                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                        }
-                        if (cx + r <= G.gx - 1) {
-                            const uint32_t s = cell_start[row + cx + r], e = cell_start[row + cx + r + 1];
-                            if (COUNT && sub == 0) { npts += e - s; nruns += 1; }
-                            coop_scan_exact(pts, s, e, sub, qx, qy, qz, bd, bi);
-                        }
-                    }
-                }
-            }
+        if (r > 1) {   // ---- shell r (rare on dense clouds): rows walked in the same order by the whole group ----
+            coop_scan_cube_or_shell<COUNT>(G, pts, cell_start, cx, cy, cz, r, false, sub, qx, qy, qz, bd, bi, npts, nruns);
             coop_argmin8(bd, bi);
         }
-        double bound = __builtin_huge_val();
-        if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
-        if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
-        if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
-        if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
-        if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
-        if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
-        if (bound == __builtin_huge_val()) break;
-        bound -= slack;
-        if (bound > 0.0 && bd <= bound * bound) break;
+        const double bound = cube_bound(G, cx, cy, cz, r, qx, qy, qz);
+        if (bound == __builtin_huge_val() || (bound > 0.0 && bd <= bound * bound)) break;
     }
 }
 
@@ -1478,8 +1515,8 @@ __device__ __forceinline__ void block_argmin256(double &d, uint32_t &i, double *
 // Same arithmetic and the same termination bound as coop_nn_search.
 // INFLATE = false: plain nearest neighbour of the (fp32-valued) points in qpts -- no early-out, no radius.
 template <bool INFLATE>
-__global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const float4 *__restrict__ pts,
-                                                            const uint32_t *__restrict__ cell_start, InflateParams P,
+__global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const float4 *__restrict__ pts0,
+                                                            const uint32_t *__restrict__ cs0, CoarseLevels C, InflateParams P,
                                                             const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
                                                             ExpressOut *__restrict__ out)
 {
@@ -1496,13 +1533,18 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const fl
     }
     const float qxf = (float)px, qyf = (float)py, qzf = (float)pz;                    // searchPoint.x = search_Pt(0), :125-128
     const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
-    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
-    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
-    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
-    const double slack = G.hd * (1.0 / 256.0);
     double bd = __builtin_huge_val();
     uint32_t bi = kNoIndex;
-    for (int r = 1;; r++) {
+    // steps: cube r=1 of the fine level, cube r=1 of every coarser level, then shells r=2,3,.. of the coarsest level
+    for (int step = 0;; step++) {
+        const int lvl = min(step, C.n);                       // 0 = fine, 1..C.n = coarse level lvl-1
+        const int r = step <= C.n ? 1 : step - C.n + 1;
+        const GridDesc &G = lvl == 0 ? G0 : C.G[lvl - 1];
+        const float4 *pts = lvl == 0 ? pts0 : C.pts[lvl - 1];
+        const uint32_t *cell_start = lvl == 0 ? cs0 : C.cell_start[lvl - 1];
+        const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+        const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+        const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
         const int x0 = max(cx - r, 0), x1 = min(cx + r, G.gx - 1);
         const int y0 = max(cy - r, 0), y1 = min(cy + r, G.gy - 1);
         const int z0 = max(cz - r, 0), z1 = min(cz + r, G.gz - 1);
@@ -1518,15 +1560,8 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G, const fl
             }
         }
         block_argmin256(bd, bi, s_d, s_i);
-        double bound = __builtin_huge_val();
-        if (cx - r > 0) bound = fmin(bound, qx - (G.oxd + (double)(cx - r) * G.hd));
-        if (cx + r < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(cx + r + 1) * G.hd) - qx);
-        if (cy - r > 0) bound = fmin(bound, qy - (G.oyd + (double)(cy - r) * G.hd));
-        if (cy + r < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(cy + r + 1) * G.hd) - qy);
-        if (cz - r > 0) bound = fmin(bound, qz - (G.ozd + (double)(cz - r) * G.hd));
-        if (cz + r < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(cz + r + 1) * G.hd) - qz);
-        if (bound == __builtin_huge_val()) break;
-        bound -= slack;
+        const double bound = cube_bound(G, cx, cy, cz, r, qx, qy, qz);
+        if (bound == __builtin_huge_val()) break;             // the cube covers the whole box: every point has been seen
         if (bound > 0.0 && (bd <= bound * bound || bound * bound >= stop_d2)) break;
     }
     if (threadIdx.x == 0) {

@@ -415,3 +415,26 @@ def test_pointcloud2_payload(E, oracle):
     i1, d1 = c.nn(q)
     assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
     c.close()
+
+
+@pytest.mark.parametrize("pyramid", [False, True])
+def test_sparse_occupancy_clouds(E, oracle, pyramid, monkeypatch):
+    """Clouds whose points sit on surfaces: queries in free space (far from every point) and far outside the box must
+    still return the exact neighbour, through the batch kernel and the express path -- with plain shell expansion
+    (default) and with the optional coarser index levels (PCT_PYRAMID_EMPTY_FRAC)."""
+    if pyramid:
+        monkeypatch.setenv("PCT_PYRAMID_EMPTY_FRAC", "0.5")
+    for pts in (synth.pillar_map(), synth.clustered_points(131, 300000, 0, 60)):
+        lo, hi = pts.min(0), pts.max(0)
+        u = synth.uniform01_f32(132, 3 * 30000).reshape(-1, 3)
+        q = np.concatenate([(lo + u * (hi - lo)).astype(np.float32), synth.uniform_points(133, 300, -80, 140)])
+        bi, bd = oracle.brute_nearest(pts, q)
+        c = make_cloud(E, pts, grid=True)
+        ig, dg = c.nn(q, E.ALGO_GRID)                         # batch kernel (8 lanes per query)
+        assert np.array_equal(dg, bd) and np.array_equal(ig.astype(np.int64), bi.astype(np.int64))
+        ie, de = c.nn(q[:700], E.ALGO_GRID)                   # <= 1024 queries: block-per-query express kernel
+        assert np.array_equal(de, bd[:700]) and np.array_equal(ie.astype(np.int64), bi[:700].astype(np.int64))
+        prm = E.inflate_params(tuple(float(v) for v in (lo + hi) / 2), 1e9, 0.25, 1.5)
+        rad, _, _ = c.inflate(prm, q[:500].astype(np.float64))    # with idx/d2 requested: exact search
+        assert np.array_equal(rad, np.minimum(np.sqrt(bd[:500]) - 0.25, 1.5))
+        c.close()
