@@ -142,9 +142,12 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
                      int64_t *first_hit, int64_t *nsamples,
                      int64_t cap, double *pos, double *radius, double *d2, uint32_t *idx);
 
-/* ---- batch queries, DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = the
- * library's own stream).  For torch.distributed sharding and graph capture.  An empty
- * shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ------------------------------------ */
+/* ---- batch queries, DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = HIP's null
+ * stream, as in any HIP call -- that is also PyTorch's default stream).  Every kernel of the batch is
+ * ordered on that stream and nothing else, so work the caller queues behind it (a collective, a copy)
+ * sees the results.  One batch at a time per cloud: the cloud's scratch buffers are shared, so do not
+ * issue batches on the same cloud from two streams concurrently.  For torch.distributed sharding and
+ * graph capture.  An empty shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ---------------------- */
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream);
 /* make sure workspaces for batches up to Q exist (call before capturing a graph) */

@@ -567,7 +567,7 @@ int pct_init(int device)
 int pct_sync(void)
 {
     PCTCHK(require_init());
-    HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipDeviceSynchronize());    // the library's stream and any caller stream handed to the *_dev entry points
     return PCT_OK;
 }
 
@@ -891,13 +891,13 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream)
 {
     if (!c || Q < 0 || (Q > 0 && (!d_q || !d_idx || !d_d2))) return fail(PCT_ERR_INVALID, "bad nn_batch_dev arguments");
-    return nn_dev(c, algo, d_q, Q, d_idx, d_d2, stream ? (hipStream_t)stream : g_stream);
+    return nn_dev(c, algo, d_q, Q, d_idx, d_d2, (hipStream_t)stream);   // NULL = HIP's null stream (torch's default stream)
 }
 
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream)
 {
     if (!c || Q < 0 || (Q > 0 && (!d_q || !d_r || !d_count))) return fail(PCT_ERR_INVALID, "bad radius_count_batch_dev arguments");
-    return count_dev(c, algo, d_q, d_r, Q, d_count, stream ? (hipStream_t)stream : g_stream);
+    return count_dev(c, algo, d_q, d_r, Q, d_count, (hipStream_t)stream);
 }
 
 // ---- host-buffer entry points ----------------------------------------------------------

@@ -109,24 +109,66 @@ class ShardedCloud:
         if len(self.cloud):
             self.cloud.build_grid(cell_size)
 
-    def reserve(self, Q: int):
+    def reserve(self, Q: int, depth: int = 2):
+        """Result buffers for batches of up to Q queries; `depth` sets of them so that the exchange step of one
+        batch can overlap the kernels of the next (nn_submit)."""
         self.cloud.reserve_queries(Q)
-        self._idx32 = torch.empty(Q, dtype=torch.int32, device=self.device)
-        self._d2 = torch.empty(Q, dtype=torch.float64, device=self.device)
+        self._slots = [(torch.empty(Q, dtype=torch.int32, device=self.device),
+                        torch.empty(Q, dtype=torch.float64, device=self.device)) for _ in range(max(depth, 1))]
+        self._idx32, self._d2 = self._slots[0]
         self._cnt = torch.empty(Q, dtype=torch.int32, device=self.device)
+        self._slot_free = [None] * len(self._slots)   # event: the exchange that last read this slot has finished
+        self._next_slot = 0
+        self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+
+    def _nn_into(self, q: torch.Tensor, algo: int, idx32: torch.Tensor, d2: torch.Tensor):
+        Q = q.shape[0]
+        s = torch.cuda.current_stream().cuda_stream
+        self.cloud.nn_device(q.data_ptr(), Q, idx32.data_ptr(), d2.data_ptr(), s, algo)
+        if self.world > 1 and self.n_total < 2 ** 31 - 1:
+            # indices < 2^31 are exchanged as int32 (the u32 bit pattern is non-negative; NO_INDEX -> INT32_MAX)
+            i32 = idx32[:Q]
+            return d2[:Q], torch.where(i32 < 0, torch.full_like(i32, torch.iinfo(torch.int32).max), i32)
+        # u32 -> int64 (NO_INDEX stays recognisable through d2 == +inf)
+        return d2[:Q], idx32[:Q].to(torch.int64) & 0xFFFFFFFF
 
     def nn_local(self, q: torch.Tensor, algo: int = 0):
         """Per-shard kernel on torch's current stream.  q: float32 [Q,3] on this device."""
-        Q = q.shape[0]
-        s = torch.cuda.current_stream().cuda_stream
-        self.cloud.nn_device(q.data_ptr(), Q, self._idx32.data_ptr(), self._d2.data_ptr(), s, algo)
-        if self.world > 1 and self.n_total < 2 ** 31 - 1:
-            # indices < 2^31 are exchanged as int32 (the u32 bit pattern is non-negative; NO_INDEX -> INT32_MAX)
-            i32 = self._idx32[:Q]
-            return self._d2[:Q], torch.where(i32 < 0, torch.full_like(i32, torch.iinfo(torch.int32).max), i32)
-        # u32 -> int64 (NO_INDEX stays recognisable through d2 == +inf)
-        idx = self._idx32[:Q].to(torch.int64) & 0xFFFFFFFF
-        return self._d2[:Q], idx
+        return self._nn_into(q, algo, self._idx32, self._d2)
+
+    def nn_submit(self, q: torch.Tensor, algo: int = 0):
+        """Pipelined form of nn(): the shard kernels run on the current stream into the next result slot, the
+        exchange step runs behind them on a side stream, and the call returns at once with
+        (d2, idx, done_event).  The next batch's kernels therefore overlap this batch's all_reduce pair
+        (8+4 bytes per query over xGMI, which at Q = 1M costs about as much as the kernels).  The consumer waits
+        on done_event (torch.cuda.current_stream().wait_event(ev) or ev.synchronize()) before reading."""
+        if self.world == 1:
+            d2, idx = self.nn_local(q, algo)
+            ev = torch.cuda.Event()
+            ev.record()
+            return d2, idx, ev
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % len(self._slots)
+        cur = torch.cuda.current_stream()
+        if self._slot_free[slot] is not None:
+            cur.wait_event(self._slot_free[slot])       # the exchange `depth` batches ago still owns these buffers
+        idx32, d2buf = self._slots[slot]
+        d2, idx = self._nn_into(q, algo, idx32, d2buf)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self._comm):
+            self._comm.wait_event(ready)
+            idx.record_stream(self._comm)
+            if idx.is_cuda and dist.get_backend(self.group) == "gloo":
+                best, cand = merge_nearest(d2, idx, self.group)         # rehearsal: staged through the host
+            else:
+                best, cand = _merge_nearest(d2, idx, self.group)
+            done = torch.cuda.Event()
+            done.record(self._comm)
+        self._slot_free[slot] = done
+        best.record_stream(cur)
+        cand.record_stream(cur)
+        return best, cand, done
 
     def nn(self, q: torch.Tensor, algo: int = 0):
         d2, idx = self.nn_local(q, algo)

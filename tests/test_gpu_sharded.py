@@ -1,0 +1,68 @@
+"""GPU test of pointcloudtraj_amd.dist.ShardedCloud end to end: two ranks (gloo, both on the box's one card),
+each holding a contiguous index-range shard in HBM and running the HIP kernels; the merged answers of nn() and of
+the pipelined nn_submit() must equal the single-cloud oracle bit for bit (indices and fp64 d2), ties included.
+With RCCL on a multi-GPU node the same code path keeps the tensors in HBM (dist._staging)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from test_dist_gloo import ROOT, _free_port
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", PCT_DIST_BACKEND="gloo")
+    import torch
+    import torch.distributed as dist
+    from pointcloudtraj_amd import dist as D, engine as E, synth
+    D.init_process_group_from_env()
+    base = synth.clustered_points(8, 60_000, 0, 30)
+    pts = np.concatenate([synth.uniform_points(7, 80_000, 0, 30), base, base])     # exact ties across the two shards
+    sc = D.ShardedCloud(len(pts), rank, world, 0)
+    sc.set_input_local(pts[sc.begin:sc.end])
+    sc.build_grid()
+    batches = [np.concatenate([synth.uniform_points(20 + k, 20_000, -3, 33), base[k::97][:500]]) for k in range(4)]
+    sc.reserve(max(len(b) for b in batches))
+    outs = []
+    for k, qh in enumerate(batches):
+        q = torch.from_numpy(qh).to(sc.device)
+        if k == 0:
+            d2, idx = sc.nn(q, E.ALGO_GRID)
+            outs.append((d2, idx, None))
+        else:
+            outs.append(sc.nn_submit(q, E.ALGO_GRID if k % 2 else E.ALGO_STREAM))   # queued back to back, read afterwards
+    cq = torch.from_numpy(batches[0]).to(sc.device)
+    cnt = sc.radius_count(cq, torch.full((len(cq),), 1.5, dtype=torch.float32, device=sc.device))
+    if rank == 0:
+        from oracle import oracle as O
+        bad = []
+        for k, ((d2, idx, ev), qh) in enumerate(zip(outs, batches)):
+            if ev is not None:
+                ev.synchronize()
+            wi, wd = O.brute_nearest(pts, qh)
+            nd = int((d2.cpu().numpy() != wd).sum())
+            ni = int((idx.cpu().numpy() != wi.astype(np.int64)).sum())
+            if nd or ni:
+                bad.append(f"batch {k}: {nd} d2 and {ni} index mismatches")
+        nc = int((cnt.cpu().numpy() != O.brute_count(pts, batches[0], 1.5).astype(np.int64)).sum())
+        if nc:
+            bad.append(f"{nc} count mismatches")
+        with open(os.path.join(out_dir, "ok"), "w") as f:
+            f.write("; ".join(bad) if bad else "1")
+    torch.cuda.synchronize()
+    dist.barrier()
+    sc.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_cloud_on_one_card(tmp_path):
+    from oracle import oracle as O
+    O.build()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert open(tmp_path / "ok").read() == "1"
