@@ -143,10 +143,14 @@ class ShardedCloud:
         (8+4 bytes per query over xGMI, which at Q = 1M costs about as much as the kernels).  The consumer waits
         on done_event (torch.cuda.current_stream().wait_event(ev) or ev.synchronize()) before reading."""
         if self.world == 1:
-            d2, idx = self.nn_local(q, algo)
+            # nothing to merge: hand back the engine's own buffers (idx = the u32 indices as an int32 view, no
+            # conversion kernel in the step; PCT_NO_INDEX reads as -1)
+            Q = q.shape[0]
+            self.cloud.nn_device(q.data_ptr(), Q, self._idx32.data_ptr(), self._d2.data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream, algo)
             ev = torch.cuda.Event()
             ev.record()
-            return d2, idx, ev
+            return self._d2[:Q], self._idx32[:Q], ev
         slot = self._next_slot
         self._next_slot = (slot + 1) % len(self._slots)
         cur = torch.cuda.current_stream()
