@@ -124,7 +124,7 @@ struct pct_cloud {
     float4 *d_qsorted = nullptr;
     float4 *d_sorttmp = nullptr;                                                // {x,y,z,id} records of the two-level sort
     uint32_t *d_sortkey = nullptr;                                              // their keys
-    uint32_t *d_sort1 = nullptr;                                                // total1 | start1(+1) | cursor1
+    uint32_t *d_sort1 = nullptr;                                                // total1 | start1(+1) | fill1
     // query workspaces
     int64_t qcap = 0;
     float *d_q = nullptr, *d_r = nullptr;
@@ -355,13 +355,16 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         // two-level counting sort on LDS histograms (kernels.hpp)
         int key_shift = 0;
         while ((((uint64_t)B.nbins - 1) >> key_shift) >= (1ull << 20)) key_shift++;
-        uint32_t *total1 = c->d_sort1, *start1 = c->d_sort1 + kSortBuckets, *cursor1 = c->d_sort1 + 2 * kSortBuckets + 4;
-        const int nb = ceil_div(Q, kSortPerBlock);
-        HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));
-        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, d_q, (uint32_t)Q, c->d_qbin, total1);
-        qsort_scan1_kernel<<<1, 256, 0, s>>>(total1, start1, cursor1);
-        qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, cursor1, c->d_sortkey, c->d_sorttmp);
-        qsort_fine_kernel<<<kSortBuckets, 256, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, c->d_perm, c->d_qsorted);
+        uint32_t *total1 = c->d_sort1, *start1 = c->d_sort1 + kSortBuckets, *fill1 = c->d_sort1 + 2 * kSortBuckets + 4;
+        static const int per_block_env = [] { const char *e = std::getenv("PCT_SORT_PER_BLOCK"); return e ? std::max(1024, std::atoi(e)) : 0; }();
+        // ~128 blocks: small batches want parallelism (64 K queries: 21 us at 1024 per block, 36 us at 8192), large ones
+        // want long per-block bucket slices (1 M: 67 us at 8192, 87 us at 1024)
+        const uint32_t per_block = per_block_env ? (uint32_t)per_block_env
+                                                 : (uint32_t)std::min<int64_t>(kSortPerBlock, std::max<int64_t>(1024, (Q / 128 + 1023) / 1024 * 1024));
+        const int nb = ceil_div(Q, (int64_t)per_block);
+        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, d_q, (uint32_t)Q, per_block, c->d_qbin, total1, fill1);
+        qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, total1, fill1, start1, c->d_sortkey, c->d_sorttmp);
+        qsort_fine_kernel<<<kSortBuckets, 256, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, c->d_perm, c->d_qsorted);
         HIPCHK(hipGetLastError());
         *perm_out = c->d_perm;
         return PCT_OK;
@@ -746,7 +749,10 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_qsorted, q));
     PCTCHK(dev_alloc(&c->d_sorttmp, q));
     PCTCHK(dev_alloc(&c->d_sortkey, q));
-    if (!c->d_sort1) PCTCHK(dev_alloc(&c->d_sort1, 3 * kSortBuckets + 8));
+    if (!c->d_sort1) {
+        PCTCHK(dev_alloc(&c->d_sort1, 3 * kSortBuckets + 8));
+        HIPCHK(hipMemset(c->d_sort1, 0, sizeof(uint32_t) * (3 * kSortBuckets + 8)));   // the sort keeps total1 zero between batches
+    }
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)q * kMaxParts));
     PCTCHK(dev_alloc(&c->d_part_idx, (size_t)q * kMaxParts));
     c->qcap = q;

@@ -751,16 +751,24 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
 // buckets), level 2 = key & 1023 inside a bucket.  Global atomics are one per (block, non-empty
 // bucket); everything else is LDS atomics and coalesced traffic.
 constexpr int kSortBuckets = 1024;
-constexpr int kSortPerBlock = 8192;      // queries per block in the level-1 kernels
+constexpr int kSortPerBlock = 8192;      // most queries per block in the level-1 kernels (engine.hip picks 1024..8192 by batch size)
 
+//
+// Three dependent launches per batch (hist -> scatter1 -> fine); at <= 256 K queries the sort is launch-latency-bound
+// (~40 us for five dependent operations, measured), so the bucket scan lives inside scatter1 and the two counter
+// arrays are re-zeroed by the kernels themselves instead of by memsets: total1 is zero on entry (zeroed at allocation,
+// then by the fine kernel of the previous batch), fill1 is zeroed here, before any scatter1 block can touch it.
 __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, const float *__restrict__ q,
-                                                          uint32_t Q, uint32_t *__restrict__ keys, uint32_t *__restrict__ total1)
+                                                          uint32_t Q, uint32_t per_block, uint32_t *__restrict__ keys,
+                                                          uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1)
 {
     __shared__ uint32_t h[kSortBuckets];
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < kSortBuckets; i += 1024) fill1[i] = 0;
     for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kSortPerBlock;
-    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+    const uint32_t base = blockIdx.x * per_block;
+    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
         const uint32_t t = base + i;
         if (t < Q) {
             const uint32_t key = query_bin(G, B, q[3 * t], q[3 * t + 1], q[3 * t + 2]) >> key_shift;
@@ -773,17 +781,22 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
         if (h[i]) atomicAdd(&total1[i], h[i]);
 }
 
-// single block: start1 = exclusive scan of total1 (kSortBuckets entries, +1 terminator); cursor1 = copy
-__global__ __launch_bounds__(256) void qsort_scan1_kernel(const uint32_t *__restrict__ total1, uint32_t *__restrict__ start1,
-                                                          uint32_t *__restrict__ cursor1)
+// level 1 scatter: the query record {x, y, z, bitcast(id)} travels with its key, so the fine pass
+// never gathers from the (randomly ordered) input again.  Every block scans the 1024 bucket totals itself
+// (thread i = bucket i) instead of waiting for a one-block scan kernel; block 0 publishes the starts for the fine pass.
+__global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__restrict__ keys, const float *__restrict__ q,
+                                                              uint32_t Q, uint32_t per_block, const uint32_t *__restrict__ total1,
+                                                              uint32_t *__restrict__ fill1, uint32_t *__restrict__ start1,
+                                                              uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec)
 {
-    __shared__ uint32_t s_wave[4];
+    static_assert(kSortBuckets == 1024, "one thread per bucket");
+    __shared__ uint32_t h[kSortBuckets];
+    __shared__ uint32_t basepos[kSortBuckets];
+    __shared__ uint32_t s_wave[16];
+    h[threadIdx.x] = 0;
+    const uint32_t tot = total1[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = total1[threadIdx.x * 4 + k];
-    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-    uint32_t inc = tsum;
+    uint32_t inc = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)inc, off, kWave);
@@ -791,39 +804,25 @@ __global__ __launch_bounds__(256) void qsort_scan1_kernel(const uint32_t *__rest
     }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t run = inc - tsum;
-    for (int w = 0; w < wave; w++) run += s_wave[w];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        start1[threadIdx.x * 4 + k] = run;
-        cursor1[threadIdx.x * 4 + k] = run;
-        run += v[k];
+    uint32_t start = inc - tot;
+    for (int w = 0; w < wave; w++) start += s_wave[w];
+    if (blockIdx.x == 0) {
+        start1[threadIdx.x] = start;
+        if (threadIdx.x == kSortBuckets - 1) start1[kSortBuckets] = start + tot;
     }
-    if (threadIdx.x == 255) start1[kSortBuckets] = run;
-}
-
-// level 1 scatter: the query record {x, y, z, bitcast(id)} travels with its key, so the fine pass
-// never gathers from the (randomly ordered) input again
-__global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__restrict__ keys, const float *__restrict__ q,
-                                                              uint32_t Q, uint32_t *__restrict__ cursor1,
-                                                              uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec)
-{
-    __shared__ uint32_t h[kSortBuckets];
-    __shared__ uint32_t basepos[kSortBuckets];
-    for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
-    __syncthreads();
-    const uint32_t base = blockIdx.x * kSortPerBlock;
-    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+    const uint32_t base = blockIdx.x * per_block;
+    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
         const uint32_t t = base + i;
         if (t < Q) atomicAdd(&h[keys[t] >> 10], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kSortBuckets; i += 1024) {
-        basepos[i] = h[i] ? atomicAdd(&cursor1[i], h[i]) : 0u;     // reserve this block's slice of bucket i
-        h[i] = 0;
+    {
+        const uint32_t mine = h[threadIdx.x];
+        basepos[threadIdx.x] = mine ? start + atomicAdd(&fill1[threadIdx.x], mine) : 0u;   // this block's slice of the bucket
+        h[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kSortPerBlock; i += 1024) {
+    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
         const uint32_t t = base + i;
         if (t < Q) {
             const uint32_t key = keys[t];
@@ -836,12 +835,13 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
 
 // one block per level-1 bucket: counting sort by the low 10 key bits, then emit perm / qsorted
 __global__ __launch_bounds__(256) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
-                                                         const uint32_t *__restrict__ start1,
+                                                         const uint32_t *__restrict__ start1, uint32_t *__restrict__ total1,
                                                          uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
 {
     __shared__ uint32_t h[kSortBuckets];
     __shared__ uint32_t s_wave[4];
     const uint32_t s = start1[blockIdx.x], e = start1[blockIdx.x + 1];
+    if (threadIdx.x == 0) total1[blockIdx.x] = 0;      // its last reader (scatter1) has finished: ready for the next batch
     if (s == e) return;
     for (int i = threadIdx.x; i < kSortBuckets; i += 256) h[i] = 0;
     __syncthreads();

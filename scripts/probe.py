@@ -78,3 +78,11 @@ if what in ("all", "grid"):
     med, mn = timeit(1 << 20, E.ALGO_GRID)
     print(f"grid ppc=2.0 SORTED queries Q=1M median={med*1e3:9.1f}us  {(1<<20)/(med*1e-3):.3e} q/s", flush=True)
     q = q_save
+
+if what == "sort":   # batch vs kernel-only time with the default grid (env knobs are read once per process: one run per setting)
+    c.build_grid()
+    E.sync()
+    for Q in (1 << 16, 1 << 18, 1 << 20):
+        med, mn = timeit(Q, E.ALGO_GRID, reps=20)
+        kmed, kmn = timeit(Q, E.ALGO_GRID, reps=20, batch=False)
+        print(f"sort probe fine={os.environ.get('PCT_SORT_FINE', '1')} shift={os.environ.get('PCT_BIN_SHIFT', '1')} Q={Q:8d} batch median={med*1e3:7.1f}us min={mn*1e3:7.1f}us  kernel median={kmed*1e3:7.1f}us min={kmn*1e3:7.1f}us", flush=True)
