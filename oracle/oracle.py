@@ -392,3 +392,58 @@ class PortCorridor:
         pe, gn, nn, ni = C.c_int(), C.c_int(), C.c_int64(), C.c_uint64()
         self.L.orrt_status(self.h, C.byref(pe), C.byref(gn), C.byref(nn), C.byref(ni))
         return dict(path_exists=bool(pe.value), global_navi=bool(gn.value), nodes=nn.value, inflation_queries=ni.value)
+
+
+class PortVoxelMap:
+    """oracle/voxel_port.c: sequential restatement of voxel_map / voxel_value_map (voxel_map.cpp:5-76)."""
+
+    def __init__(self, res: float):
+        L = port_lib()
+        L.ovox_create.restype = C.c_void_p
+        L.ovox_create.argtypes = [C.c_double]
+        L.ovox_destroy.argtypes = [C.c_void_p]
+        L.ovox_size.restype = C.c_int64
+        L.ovox_size.argtypes = [C.c_void_p]
+        L.ovox_add.restype = C.c_int64
+        L.ovox_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.ovox_get_keys.argtypes = [C.c_void_p, _i32p]
+        L.ovox_get_f64.argtypes = [C.c_void_p, _f64p]
+        L.ovox_get_f32.argtypes = [C.c_void_p, _f32p]
+        self.L = L
+        self.h = L.ovox_create(float(res))
+
+    def close(self):
+        if self.h:
+            self.L.ovox_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __len__(self):
+        return int(self.L.ovox_size(self.h))
+
+    def add(self, pts: np.ndarray):
+        """pts: [n, >=3] float32 or float64 (row stride = the array's).  Returns (n_new, is_new[n], voxel_index[n])."""
+        pts = np.ascontiguousarray(pts)
+        assert pts.dtype in (np.float32, np.float64) and pts.ndim == 2 and pts.shape[1] >= 3
+        n = len(pts)
+        is_new = np.zeros(n, np.uint8)
+        index = np.zeros(n, np.int32)
+        n_new = self.L.ovox_add(self.h, pts.ctypes.data, n, pts.strides[0], int(pts.dtype == np.float64),
+                                is_new.ctypes.data, index.ctypes.data)
+        return int(n_new), is_new, index
+
+    def keys(self):
+        out = np.zeros((len(self), 3), np.int32)
+        self.L.ovox_get_keys(self.h, out)
+        return out
+
+    def cloud_f64(self):
+        out = np.zeros((len(self), 3), np.float64)
+        self.L.ovox_get_f64(self.h, out)
+        return out
+
+    def cloud_f32(self):
+        out = np.zeros((len(self), 3), np.float32)
+        self.L.ovox_get_f32(self.h, out)
+        return out

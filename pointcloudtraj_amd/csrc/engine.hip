@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/pct_engine.h"
+#include "engine_internal.hpp"
 #include "kernels.hpp"
 
 using namespace pct;
@@ -542,9 +543,23 @@ int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_
 // ======================================================================================
 //  C ABI
 // ======================================================================================
+namespace pct_internal {
+hipStream_t stream() { return g_stream; }
+int require_init() { return ::require_init(); }
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace pct_internal
+
 extern "C" {
 
 const char *pct_last_error(void) { return g_err; }
+
 
 int pct_device_count(void)
 {
