@@ -447,3 +447,76 @@ class PortVoxelMap:
         out = np.zeros((len(self), 3), np.float32)
         self.L.ovox_get_f32(self.h, out)
         return out
+
+
+# ---- oracle/traj_port.c: Bezier evaluators beside the collision check ------------------------------------------------
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+
+
+def _traj_lib():
+    L = port_lib()
+    if not getattr(L, "_traj_bound", False):
+        L.otraj_state.argtypes = [_f64p, C.c_int, C.c_double, _f64p]
+        L.otraj_wire_from_matrix.restype = C.c_int64
+        L.otraj_wire_from_matrix.argtypes = [_f64p, C.c_int64, _i32p, C.c_int32, _f64p, _f64p, _f64p]
+        L.otraj_wire_sample.argtypes = [_f64p, _f64p, _f64p, _f64p, _u32p, C.c_int32, C.c_int32, _f64p, _f64p]
+        L.otraj_segm_index.argtypes = [_f64p, _f64p, _f64p, _f64p, _u32p, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.otraj_nearest_points.restype = C.c_int64
+        L.otraj_nearest_points.argtypes = [_f64p, _f64p, _f64p, _f64p, _u32p, C.c_int32, C.c_double, _f64p, C.c_int64]
+        L.otraj_end_yaws.argtypes = [_f64p, _f64p, C.c_int64, _f64p, _f64p, _f64p]
+        L._traj_bound = True
+    return L
+
+
+def traj_state(poly_coeff, orders, seg, u):
+    pc = np.ascontiguousarray(poly_coeff, np.float64)
+    out = np.zeros((len(seg), 9))
+    L = _traj_lib()
+    for i, (s, t) in enumerate(zip(seg, u)):
+        L.otraj_state(np.ascontiguousarray(pc[s]), int(orders[s]), float(t), out[i])
+    return out
+
+
+def traj_wire_from_matrix(poly_coeff, orders):
+    pc = np.ascontiguousarray(poly_coeff, np.float64)
+    od = np.ascontiguousarray(orders, np.int32)
+    total = int(np.sum(od.astype(np.int64) + 1))
+    cx, cy, cz = np.zeros(total), np.zeros(total), np.zeros(total)
+    n = _traj_lib().otraj_wire_from_matrix(pc, pc.shape[1], od, len(od), cx, cy, cz)
+    assert n == total
+    return cx, cy, cz
+
+
+def _wire_args(w):
+    return (np.ascontiguousarray(w.coef_x, np.float64), np.ascontiguousarray(w.coef_y, np.float64), np.ascontiguousarray(w.coef_z, np.float64),
+            np.ascontiguousarray(w.time, np.float64), np.ascontiguousarray(w.order, np.uint32), len(w.time))
+
+
+def traj_wire_sample(w, samples=1001):
+    a = _wire_args(w)
+    pos, step = np.zeros((a[5] * samples, 3)), np.zeros(a[5] * samples)
+    _traj_lib().otraj_wire_sample(*a, samples, pos, step)
+    return pos, step
+
+
+def traj_segm_index(w, twirl_len):
+    segm, part = C.c_int32(), C.c_int32()
+    _traj_lib().otraj_segm_index(*_wire_args(w), float(twirl_len), C.byref(segm), C.byref(part))
+    return segm.value, part.value
+
+
+def traj_nearest_traj(w, res, twirl_len):
+    """(voxel cloud float32, samples used): to_nearest_traj through the sequential voxel container restatement"""
+    a = _wire_args(w)
+    buf = np.zeros((a[5] * 1001 + 1, 3))
+    n = _traj_lib().otraj_nearest_points(*a, float(twirl_len), buf, len(buf))
+    m = PortVoxelMap(res)
+    m.add(buf[:n])
+    return m.cloud_f32(), int(n)
+
+
+def traj_end_yaws(path_x, path_y, coef_x, coef_y):
+    px, py = np.ascontiguousarray(path_x, np.float64), np.ascontiguousarray(path_y, np.float64)
+    out = np.zeros(len(px))
+    _traj_lib().otraj_end_yaws(px, py, len(px), np.ascontiguousarray(coef_x, np.float64), np.ascontiguousarray(coef_y, np.float64), out)
+    return out

@@ -35,8 +35,8 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIB, exist_ok=True)
     hdrs = [os.path.join(ROOT, "include", "pct_engine.h"), os.path.join(ROOT, "include", "kdtree", "kdtree.h"),
             os.path.join(ROOT, "include", "kdtree", "kdtree_ext.h")]
-    hdrs.append(os.path.join(ROOT, "include", "pct_voxel.h"))
-    eng_units = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "voxel.hip")]
+    hdrs += [os.path.join(ROOT, "include", "pct_voxel.h"), os.path.join(ROOT, "include", "pct_traj.h")]
+    eng_units = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "voxel.hip"), os.path.join(CSRC, "traj.hip")]
     eng_src = eng_units + [os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "engine_internal.hpp")]
     if force or _stale(ENGINE_SO, eng_src + hdrs):
         cmd = [HIPCC, *COMMON, "-o", ENGINE_SO, *eng_units]
