@@ -108,6 +108,15 @@ int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const fl
  * ascending index order; returns the count through *n_out (may exceed cap; only cap written). */
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
 int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+/* The same crop with everything its consumer builds from it: idx_out[cap], d2_out[cap] (fp64, kdtree.c arithmetic) and
+ * xyz_out[cap*3] (the cropped cloud = pcl::PointCloud(cloud, indices)); any of the three may be NULL.  Order: ascending
+ * index, or -- sort_by_distance != 0 -- nearest first with ties in ascending index, the order pcl's radiusSearch returns
+ * (PCL's own fp32 distances are parity-unpinned; cap must then hold every hit).  *n_out = number of hits. */
+int pct_radius_crop(pct_cloud *c, const double q[3], double r, int sort_by_distance, int64_t cap, uint32_t *idx_out, double *d2_out,
+                    float *xyz_out, int64_t *n_out);
+/* dst := the points of src within r of q, in src's order, device to device (camera_sensor.cpp:398-401 known_map_pcl;
+ * a lidar frame cropped out of a resident world map).  dst's cell index is dropped; rebuild it with pct_cloud_build_grid. */
+int pct_cloud_crop_to(pct_cloud *src, const double q[3], double r, pct_cloud *dst);
 /* K range queries against a SMALL cloud (<= 65536 points) in one launch.  ids_out[k*cap_per_query + j] in arrival order;
  * counts_out[k] >= 0: number of hits, all stored; < 0: -(number of hits), list truncated -- ask that query alone. */
 int pct_radius_indices_batch_q64(pct_cloud *c, const double *q, const double *r, int64_t K, uint32_t *ids_out, int64_t cap_per_query,

@@ -124,6 +124,24 @@ public:
         return out;
     }
 
+    // lidar sensor (camera_sensor.cpp:133-145): the points within max_dist of the sensor become this frame's observed map
+    void cropTo(const double center[3], double radius, ObstacleMap &observed)
+    {
+        check(pct_cloud_crop_to(cloud_, center, radius, observed.cloud_), "pct_cloud_crop_to");
+        observed.cloud_empty_ = pct_cloud_size(observed.cloud_) == 0;
+        if (!observed.cloud_empty_) check(pct_cloud_build_grid(observed.cloud_, 0.0f), "pct_cloud_build_grid");
+    }
+    // supervisor (status_inspector.cpp:33-46): nearestKSearch(point, 1) and sqrt(d2) < col_rad
+    bool collides(const double p[3], double col_rad)
+    {
+        if (cloud_empty_) return false;
+        const float q[3] = { (float)p[0], (float)p[1], (float)p[2] };       // pcl::PointXYZ(cmd.position.x, ...)
+        uint32_t idx;
+        double d2;
+        check(pct_nn_batch(cloud_, q, 1, &idx, &d2), "pct_nn_batch");
+        return std::sqrt(d2) < col_rad;
+    }
+
     int64_t size() const { return pct_cloud_size(cloud_); }
     bool empty() const { return cloud_empty_; }
     pct_cloud *handle() { return cloud_; }

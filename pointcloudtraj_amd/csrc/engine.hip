@@ -134,6 +134,11 @@ struct pct_cloud {
     unsigned char *d_skip = nullptr;
     double *d_part_d2 = nullptr;
     uint32_t *d_part_idx = nullptr;
+    // order-preserving crop (lidar): tile counts and the compacted {index, d2, x, y, z} of the last crop
+    uint32_t *crop_tile = nullptr, *crop_idx = nullptr;
+    double *crop_d2 = nullptr;
+    float *crop_x = nullptr, *crop_y = nullptr, *crop_z = nullptr;
+    size_t crop_tiles_cap = 0, crop_cap = 0;
     // bezier
     double *d_coef = nullptr, *d_segtime = nullptr;
     int *d_orders = nullptr, *d_nsamples = nullptr;
@@ -653,6 +658,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_part_d2); dev_free(c->d_part_idx);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
+    dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -1014,6 +1020,41 @@ int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t
     return pct_radius_count_batch_algo(c, PCT_ALGO_AUTO, q, r, Q, count);
 }
 
+// order-preserving compaction of the points within r of q into c->crop_* (kernels.hpp section 1b)
+static int crop_device(pct_cloud *c, const double q[3], double r, int64_t *total_out)
+{
+    const uint32_t n = (uint32_t)c->count;
+    const uint32_t ntiles = (n + kCropTile - 1) / kCropTile;
+    if ((size_t)ntiles + 1 > c->crop_tiles_cap) {
+        dev_free(c->crop_tile);
+        c->crop_tiles_cap = 0;
+        PCTCHK(dev_alloc(&c->crop_tile, (size_t)ntiles + 1));
+        c->crop_tiles_cap = (size_t)ntiles + 1;
+    }
+    if ((size_t)n > c->crop_cap) {
+        dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
+        c->crop_cap = 0;
+        const size_t cap = std::max<size_t>((size_t)c->cap, n);
+        PCTCHK(dev_alloc(&c->crop_idx, cap)); PCTCHK(dev_alloc(&c->crop_d2, cap));
+        PCTCHK(dev_alloc(&c->crop_x, cap)); PCTCHK(dev_alloc(&c->crop_y, cap)); PCTCHK(dev_alloc(&c->crop_z, cap));
+        c->crop_cap = cap;
+    }
+    const double rr = r * r;
+    begin_timing(c, g_stream);
+    HIPCHK(hipMemsetAsync(c->crop_tile + ntiles, 0, sizeof(uint32_t), g_stream));
+    crop_count_kernel<<<(int)ntiles, 256, 0, g_stream>>>(c->x, c->y, c->z, n, q[0], q[1], q[2], rr, c->crop_tile);
+    scan_tile_sums_kernel<<<1, 256, 0, g_stream>>>(c->crop_tile, ntiles + 1);       // entry ntiles becomes the grand total
+    crop_scatter_kernel<<<(int)ntiles, 256, 0, g_stream>>>(c->x, c->y, c->z, n, q[0], q[1], q[2], rr, (uint32_t)c->index_base, c->crop_tile,
+                                                          (uint32_t)c->crop_cap, c->crop_idx, c->crop_d2, c->crop_x, c->crop_y, c->crop_z);
+    end_timing(c, g_stream);
+    HIPCHK(hipGetLastError());
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->crop_tile + ntiles, sizeof total, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    *total_out = total;
+    return PCT_OK;
+}
+
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out)
 {
     if (!q) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
@@ -1037,25 +1078,63 @@ int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *
         *n_out = total;
         return PCT_OK;
     }
-    uint32_t *d_out = nullptr, *d_cursor = nullptr;
-    PCTCHK(dev_alloc(&d_out, (size_t)std::max<int64_t>(cap, 1)));
-    int st = dev_alloc(&d_cursor, 1);
-    if (st) { dev_free(d_out); return st; }
-    hipError_t e = hipMemsetAsync(d_cursor, 0, sizeof(uint32_t), g_stream);
-    const int blocks = (int)std::min<int64_t>(4096, (c->count + 255) / 256);
-    const double rr = r * r;
-    radius_collect_kernel<<<blocks, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], rr,
-                                                         (uint32_t)c->index_base, d_out, (uint32_t)cap, d_cursor);
-    uint32_t total = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, sizeof total, hipMemcpyDeviceToHost, g_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    int64_t total = 0;
+    PCTCHK(crop_device(c, q, r, &total));                  // ascending index order, no host sort needed
     const int64_t got = std::min<int64_t>(total, cap);
-    if (e == hipSuccess && got > 0) e = hipMemcpy(idx_out, d_out, sizeof(uint32_t) * got, hipMemcpyDeviceToHost);
-    dev_free(d_out); dev_free(d_cursor);
-    if (e != hipSuccess) return fail(PCT_ERR_HIP, "radius_indices failed: %s", hipGetErrorString(e));
-    std::sort(idx_out, idx_out + got);   // ascending index order (the kernel appends in arrival order)
+    if (got > 0) {
+        HIPCHK(hipMemcpyAsync(idx_out, c->crop_idx, sizeof(uint32_t) * got, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
     *n_out = total;
     return PCT_OK;
+}
+
+// lidar crop with everything its consumer builds from it (camera_sensor.cpp:133-145, 398-401)
+int pct_radius_crop(pct_cloud *c, const double q[3], double r, int sort_by_distance, int64_t cap, uint32_t *idx_out, double *d2_out,
+                    float *xyz_out, int64_t *n_out)
+{
+    if (!c || !q || cap < 0 || !n_out) return fail(PCT_ERR_INVALID, "bad radius_crop arguments");
+    *n_out = 0;
+    if (c->count == 0) return PCT_OK;
+    int64_t total = 0;
+    PCTCHK(crop_device(c, q, r, &total));
+    *n_out = total;
+    const int64_t got = std::min<int64_t>(total, cap);
+    if (got == 0) return PCT_OK;
+    if (sort_by_distance && got < total) return fail(PCT_ERR_CAPACITY, "a distance-sorted crop needs room for all %lld hits (cap %lld)", (long long)total, (long long)cap);
+    std::vector<uint32_t> hi((size_t)got);
+    std::vector<double> hd((size_t)got);
+    std::vector<float> hx, hy, hz;
+    HIPCHK(hipMemcpyAsync(hi.data(), c->crop_idx, sizeof(uint32_t) * got, hipMemcpyDeviceToHost, g_stream));
+    HIPCHK(hipMemcpyAsync(hd.data(), c->crop_d2, sizeof(double) * got, hipMemcpyDeviceToHost, g_stream));
+    if (xyz_out) {
+        hx.resize((size_t)got); hy.resize((size_t)got); hz.resize((size_t)got);
+        HIPCHK(hipMemcpyAsync(hx.data(), c->crop_x, sizeof(float) * got, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipMemcpyAsync(hy.data(), c->crop_y, sizeof(float) * got, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipMemcpyAsync(hz.data(), c->crop_z, sizeof(float) * got, hipMemcpyDeviceToHost, g_stream));
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    std::vector<uint32_t> order((size_t)got);
+    for (int64_t i = 0; i < got; i++) order[(size_t)i] = (uint32_t)i;
+    if (sort_by_distance)     // PCL hands back radiusSearch results nearest first; ties keep ascending index (stable)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b]; });
+    for (int64_t i = 0; i < got; i++) {
+        const uint32_t k = order[(size_t)i];
+        if (idx_out) idx_out[i] = hi[k];
+        if (d2_out) d2_out[i] = hd[k];
+        if (xyz_out) { xyz_out[3 * i] = hx[k]; xyz_out[3 * i + 1] = hy[k]; xyz_out[3 * i + 2] = hz[k]; }
+    }
+    return PCT_OK;
+}
+
+// dst = the points of src within r of q, in src's order, device to device (known_map_pcl of camera_sensor.cpp:398-401)
+int pct_cloud_crop_to(pct_cloud *src, const double q[3], double r, pct_cloud *dst)
+{
+    if (!src || !dst || !q || src == dst) return fail(PCT_ERR_INVALID, "bad crop_to arguments");
+    int64_t total = 0;
+    if (src->count) PCTCHK(crop_device(src, q, r, &total));
+    if (total > dst->cap) return fail(PCT_ERR_CAPACITY, "crop holds %lld points, destination capacity is %lld", (long long)total, (long long)dst->cap);
+    return pct_cloud_upload_soa_dev(dst, src->crop_x, src->crop_y, src->crop_z, total);
 }
 
 // K range queries against a small cloud in one launch: ids_out[k * cap_per_query + j] (arrival order, not sorted),

@@ -82,6 +82,8 @@ def lib():
         L.pct_radius_count_batch.argtypes = [vp, f32p, f32p, i64, u32p]
         L.pct_radius_count_batch_algo.argtypes = [vp, i32, f32p, f32p, i64, u32p]
         L.pct_radius_indices.argtypes = [vp, f32p, C.c_float, u32p, i64, C.POINTER(i64)]
+        L.pct_radius_crop.argtypes = [vp, vp, C.c_double, C.c_int, i64, vp, vp, vp, C.POINTER(i64)]
+        L.pct_cloud_crop_to.argtypes = [vp, vp, C.c_double, vp]
         L.pct_inflate_batch.argtypes = [vp, C.POINTER(InflateParams), f64p, i64, f64p, u32p, f64p]
         L.pct_bezier_check.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.c_double, C.c_double,
                                        C.POINTER(i64), C.POINTER(i64), i64, f64p, f64p, f64p, u32p]
@@ -230,6 +232,22 @@ class Cloud:
         n = C.c_int64()
         _chk(lib().pct_radius_indices(self._h, _ptr(q), float(radius), _ptr(out), cap, C.byref(n)))
         return out[:min(n.value, cap)].copy(), n.value
+
+    def radius_crop(self, center, radius, sort_by_distance=False):
+        """lidar crop (camera_sensor.cpp:133-145): (indices u32, d2 fp64, cropped cloud float32 [k,3]) of the points within radius"""
+        q = np.ascontiguousarray(center, np.float64).reshape(3)
+        cap = max(len(self), 1)
+        idx, d2, xyz = np.empty(cap, np.uint32), np.empty(cap, np.float64), np.empty((cap, 3), np.float32)
+        n = C.c_int64()
+        _chk(lib().pct_radius_crop(self._h, q.ctypes.data, float(radius), int(bool(sort_by_distance)), cap, idx.ctypes.data,
+                                   d2.ctypes.data, xyz.ctypes.data, C.byref(n)))
+        k = min(n.value, cap)
+        return idx[:k].copy(), d2[:k].copy(), xyz[:k].copy()
+
+    def crop_to(self, center, radius, dst: "Cloud"):
+        """dst := points within radius of center, in this cloud's order, device to device"""
+        q = np.ascontiguousarray(center, np.float64).reshape(3)
+        _chk(lib().pct_cloud_crop_to(self._h, q.ctypes.data, float(radius), dst._h))
 
     def inflate(self, params: InflateParams, points):
         p = np.ascontiguousarray(points, np.float64).reshape(-1, 3)

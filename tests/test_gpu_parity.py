@@ -438,3 +438,44 @@ def test_sparse_occupancy_clouds(E, oracle, pyramid, monkeypatch):
         rad, _, _ = c.inflate(prm, q[:500].astype(np.float64))    # with idx/d2 requested: exact search
         assert np.array_equal(rad, np.minimum(np.sqrt(bd[:500]) - 0.25, 1.5))
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3000, 300_000])       # express path (host-mapped id list) and the order-preserving compaction
+def test_lidar_crop_indices_distances_and_cloud(E, oracle, n):
+    """camera_sensor.cpp:133-145 / 398-401: radiusSearch around the sensor + PointCloud(cloud, indices).  Checked against
+    the same fp64 arithmetic in numpy (no FMA: separate ufunc calls) and the oracle's brute-force count."""
+    pts = synth.pillar_map(6)[:n] if n <= 182332 else np.concatenate([synth.pillar_map(6), synth.uniform_points(61, n - 182332, -25, 25)])
+    c = E.Cloud(len(pts))
+    c.set_input(pts)
+    centre, r = np.float64([-10.0, -10.0, 2.0]), 7.5
+    d = pts.astype(np.float64) - centre
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    want = np.nonzero(d2 <= r * r)[0]
+    assert len(want) == int(oracle.brute_count(pts, centre.astype(np.float32)[None], r)[0]) and len(want) > 100
+    ids, n_hits = c.radius_indices(centre, r)
+    assert n_hits == len(want) and np.array_equal(ids, want)
+    idx, gd2, xyz = c.radius_crop(centre, r)
+    assert np.array_equal(idx, want) and np.array_equal(gd2, d2[want]) and np.array_equal(xyz, pts[want])
+    idx, gd2, xyz = c.radius_crop(centre, r, sort_by_distance=True)
+    order = np.lexsort((want, d2[want]))                 # nearest first, ties by ascending index
+    assert np.array_equal(idx, want[order]) and np.array_equal(gd2, d2[want][order]) and np.array_equal(xyz, pts[want][order])
+    # device-to-device: the crop becomes another cloud (the frame the planner sees) and answers NN like a host-built one
+    obs = E.Cloud(len(pts))
+    c.crop_to(centre, r, obs)
+    assert len(obs) == len(want)
+    obs.build_grid()
+    q = synth.uniform_points(62, 2048, -18, -2)
+    gi, gd = obs.nn(q)
+    wi, wd = oracle.brute_nearest(pts[want], q)
+    assert np.array_equal(gd, wd) and np.array_equal(gi, wi)
+    # nothing in range, and a destination that is too small
+    idx, gd2, xyz = c.radius_crop([500.0, 0.0, 0.0], 1.0)
+    assert len(idx) == 0
+    c.crop_to([500.0, 0.0, 0.0], 1.0, obs)
+    assert len(obs) == 0
+    small = E.Cloud(10)
+    with pytest.raises(E.EngineError):
+        c.crop_to(centre, r, small)
+    for k in (c, obs, small):
+        k.close()
