@@ -17,7 +17,7 @@ stats = glob.glob(os.path.join(out, "trace", "*", "*_kernel_stats.csv"))
 rows = []
 if stats:
     for r in csv.DictReader(open(stats[0])):
-        rows.append([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+        rows.append([r["Name"].replace("(anonymous namespace)::", "").split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     with open(os.path.join(out, "summary_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "average_ns", "percent", "min_ns", "max_ns"])
@@ -29,7 +29,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
-        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         if "pct::" in k:
             pmc.setdefault(k, {}).update({c: {"mean_per_launch": sum(x) / len(x), "launches": len(x)} for c, x in v.items()})
