@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void vox_insert_kernel(const unsigned char *__
     uint32_t slot = kNoSlot;
     if (vox_coords<T>(pts + (size_t)i * stride_bytes, res, ix, iy, iz)) {
         slot = vox_find_or_claim(keys, mask, vox_pack(ix, iy, iz));
-        if (slot != kNoSlot) atomicMin(&vals[slot], base + i);
-        else flags->table_full = 1;
+        if (slot == kNoSlot) flags->table_full = 1;
+        // a voxel of an earlier batch holds its final id (< base, written before this launch): nothing to decide, and the
+        // re-observation of a known map (the common case for accumulating sensors) then costs no atomic at all
+        else if (vals[slot] >= base) atomicMin(&vals[slot], base + i);
     } else {
         flags->out_of_range = 1;
     }

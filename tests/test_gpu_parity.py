@@ -479,3 +479,44 @@ def test_lidar_crop_indices_distances_and_cloud(E, oracle, n):
         c.crop_to(centre, r, small)
     for k in (c, obs, small):
         k.close()
+
+
+@pytest.mark.gpu
+def test_full_size_properties_c4_sharded_on_one_card(E, oracle):
+    """Config C4 at full size: 100 M points in [0,200)^3 (seed 6), Q = 4096 (seed 7), rank r owning indices
+    [r*N/8, (r+1)*N/8).  With one card the eight shards are visited one after the other (each through the same
+    index-base + kernel path a rank runs) and merged with the exchange step's rule (min d2, then lowest global index):
+      - the merged answer equals the answer of ONE 100 M-point cloud (cell-pruned kernel) bit for bit;
+      - brute-force (packed-fp32 filter + exact recheck over all 100 M points) agrees on a 512-query slice;
+      - the first 8 queries equal the exhaustive CPU oracle;
+      - the reported d2 is the fp64 distance to the reported point, recomputed on the host."""
+    N, Q, W = 100_000_000, 4096, 8
+    pts = synth.uniform_points(6, N, 0.0, 200.0)
+    q = synth.uniform_points(7, Q, 0.0, 200.0)
+    best_d = np.full(Q, np.inf)
+    best_i = np.full(Q, np.iinfo(np.int64).max, np.int64)
+    shard = E.Cloud(N // W + 1)
+    for r in range(W):
+        b, e = (r * N) // W, ((r + 1) * N) // W
+        shard.set_input(pts[b:e])
+        shard.set_index_base(b)
+        shard.build_grid()
+        i, d = shard.nn(q, E.ALGO_GRID)
+        i = i.astype(np.int64)
+        take = (d < best_d) | ((d == best_d) & (i < best_i))
+        best_d = np.where(take, d, best_d)
+        best_i = np.where(take, i, best_i)
+    shard.close()
+    whole = E.Cloud(N)
+    whole.set_input(pts)
+    whole.build_grid()
+    wi, wd = whole.nn(q, E.ALGO_GRID)
+    assert np.array_equal(wd, best_d) and np.array_equal(wi.astype(np.int64), best_i)
+    bi, bd = whole.nn(q[:512], E.ALGO_STREAM)
+    assert np.array_equal(bi, wi[:512]) and np.array_equal(bd, wd[:512])
+    oi, od = oracle.brute_nearest(pts, q[:8])
+    assert np.array_equal(wd[:8], od) and np.array_equal(wi[:8].astype(np.int64), oi.astype(np.int64))
+    P = pts[best_i].astype(np.float64) - q.astype(np.float64)
+    s = P[:, 0] * P[:, 0]; s = s + P[:, 1] * P[:, 1]; s = s + P[:, 2] * P[:, 2]
+    assert np.array_equal(s, best_d)
+    whole.close()
