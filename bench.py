@@ -300,7 +300,7 @@ def main():
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
         # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
-        # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches of 32 samples
+        # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches of 64 samples, one fused launch per batch
         from pointcloudtraj_amd import corridor, scenarios
         cloud1 = scenarios.sensed_cloud(12.0)
         scenarios.timed_scenario(corridor.SafeRegionRrtStar(80000), cloud1)          # warm-up (first launches, allocations)

@@ -12,6 +12,7 @@
 #define PCT_KDTREE_EXT_H
 #include <stdint.h>
 #include "kdtree/kdtree.h"
+#include "pct_engine.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -35,6 +36,18 @@ int kdx_range_candidates_batch(struct kdtree *tree, const float *pos, const floa
  * are tested here.  Same hits, same iteration order as the reference (kdtree.c:262-293, 810-828). */
 struct kdres *kdx_range_from_candidates(struct kdtree *tree, const float *pos, float range, const uint32_t *ids, int n_ids,
                                         int32_t n_snapshot);
+
+/* Per-node planner data for the fused expansion step: aux = {x, y, z, radius} -- the node's fp64 centre and its sphere
+ * radius as the steer step reads them (corridor_finder.cpp:387-404).  Defaults to the stored position and radius 0. */
+int kdx_set_node_aux(struct kdtree *tree, int32_t node, const double aux[4]);
+
+/* K RRT* iterations' queries in ONE launch against the tree as it is now (pct_rrt_expand_batch): for sample i the nearest
+ * node (as kd_nearestf on the fp32-narrowed sample), the steered centre, its inflation radius against `obstacles`, and the
+ * candidate list kdx_range_from_candidates() needs for kd_nearest_rangef(centre, 2 * float(radius)).
+ * Returns 0 on success, -1 when the fused path cannot serve this tree (more than 65536 nodes, obstacle cloud without its
+ * cell index): the caller then issues the three queries separately. */
+int kdx_expand_batch(struct kdtree *tree, pct_cloud *obstacles, const pct_inflate_params *prm, const double *samples, int k,
+                     int cap_per_query, pct_expand_result *out, uint32_t *ids);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,10 @@ int pct_corridor_check_traj_pt_col(pct_corridor *c, const double p[3], int *coll
 int pct_corridor_get_path(pct_corridor *c, double *path, double *radius, int64_t cap, int64_t *n_out);
 int pct_corridor_status(pct_corridor *c, int *path_exists, int *global_navi, int64_t *n_nodes, uint64_t *inflation_queries);
 int pct_corridor_speculation_stats(pct_corridor *c, uint64_t *replayed_from_batch, uint64_t *fell_back);
+/* on (default): one fused launch per speculative batch (nearest node -> steer -> inflation -> neighbourhood);
+ * off: the same three stages as three batched launches.  The corridor does not depend on it. */
+int pct_corridor_set_fused_expansion(pct_corridor *c, int on);
+int pct_corridor_expansion_launches(pct_corridor *c, uint64_t *launches);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,7 @@ struct CorridorNode {
     CorridorNode *preNode_ptr = nullptr;
     std::vector<CorridorNode *> nxtNode_ptr;
     float g = 0, f = 0;
+    int32_t kd_index = -1;          // node number in the kd tree (since its last rebuild): where the node's steer data lives
     CorridorNode() = default;
     CorridorNode(const Vec3 &c, float r, float g_, float f_) : coord(c), radius(r), g(g_), f(f_) {}
 };
@@ -145,6 +146,8 @@ public:
     void setSpeculation(int k) { spec_k_ = std::max(1, std::min(k, 256)); }
     uint64_t speculativeHits() const { return n_spec_hit_; }
     uint64_t speculativeFallbacks() const { return n_spec_miss_; }
+    uint64_t expansionLaunches() const { return n_launch_; }
+    void setFusedExpansion(bool on) { fused_ok_ = on; }          // off = nearest / inflation / range as three batched launches
 
     // :226-270
     void resetRoot(const Vec3 &target_coord)
@@ -218,6 +221,7 @@ public:
                 const int ret = checkNodeUpdate(update_radius, ptr->radius);
                 const double old_radius = ptr->radius;
                 ptr->radius = (float)update_radius;
+                syncNodeAux(ptr);
                 if (ret == -1) {
                     ptr->valid = false;
                     invalidSet.push_back(ptr);
@@ -381,7 +385,16 @@ private:
     void insertKd(NodePtr n)
     {
         float pos[3] = { (float)n->coord.x, (float)n->coord.y, (float)n->coord.z };
+        n->kd_index = kdx_size(kdTree_);
         kd_insertf(kdTree_, pos, n);
+        syncNodeAux(n);
+    }
+    // what the fused expansion kernel's steer step reads for this node: fp64 centre, float radius (widened)
+    void syncNodeAux(NodePtr n)
+    {
+        if (n->kd_index < 0 || n->kd_index >= kdx_size(kdTree_) || kdx_node_data(kdTree_, n->kd_index) != (void *)n) return;
+        const double aux[4] = { n->coord.x, n->coord.y, n->coord.z, (double)n->radius };
+        kdx_set_node_aux(kdTree_, n->kd_index, aux);
     }
     void recordNode(NodePtr n) { NodeList.push_back(n); }                                       // :569-573
 
@@ -436,7 +449,79 @@ private:
     // have changed them; otherwise it takes the one-by-one path, and if the sampling distribution or the kd tree itself
     // changed (path found / improved, removeInvalid rebuilt the tree) the rest of the batch is discarded and the generator
     // is rewound, so the sequence of samples is exactly the sequential one.  Returns the number of samples consumed.
-    int growBatch(int K, bool refine)
+    int growBatch(int K, bool refine) { return fused_ok_ ? growBatchFused(K, refine) : growBatchStaged(K, refine); }
+
+    // The same speculation with ONE launch per batch: kdx_expand_batch answers nearest node -> steer -> inflation ->
+    // neighbourhood candidates of every sample in a single kernel (the three stages of growBatchStaged are dependent, so
+    // staged they cost three launch + sync round trips).  When a sample's nearest node turns out to be one added earlier
+    // in the batch, the REST of the batch is re-evaluated against the tree as it is now -- one launch again, and the
+    // conflicting sample is then first in line and cannot conflict -- instead of walking that sample through three
+    // single queries.  Samples, acceptance order and results are exactly the sequential ones.
+    int growBatchFused(int K, bool refine)
+    {
+        const uint64_t epoch0 = sample_epoch_, kd_epoch0 = kd_epoch_;
+        std::vector<Vec3> sample((size_t)K);
+        std::vector<uint32_t> rng_before((size_t)K + 1);
+        for (int i = 0; i < K; i++) { rng_before[i] = eng_.state(); sample[i] = genSample(); }
+        rng_before[K] = eng_.state();
+        const int cap = 256;
+        std::vector<double> sflat((size_t)3 * K);
+        std::vector<pct_expand_result> res((size_t)K);
+        std::vector<uint32_t> ids((size_t)K * cap);
+        int pos = 0;
+        while (pos < K) {
+            const int32_t n0 = kdx_size(kdTree_);
+            const int m = K - pos;
+            for (int i = 0; i < m; i++) { sflat[3 * i] = sample[pos + i].x; sflat[3 * i + 1] = sample[pos + i].y; sflat[3 * i + 2] = sample[pos + i].z; }
+            if (kdx_expand_batch(kdTree_, map_.handle(), &map_.params(), sflat.data(), m, cap, res.data(), ids.data()) != 0) {
+                fused_ok_ = false;                                   // e.g. obstacle cloud without its cell index: staged path from here on
+                eng_.setState(rng_before[pos]);
+                return pos > 0 ? pos : growBatchStaged(K, refine);
+            }
+            n_launch_++;
+            int i = pos;
+            for (; i < K; i++) {
+                if (sample_epoch_ != epoch0 || kd_epoch_ != kd_epoch0) {   // what sample i would be, or the tree it would see, changed
+                    eng_.setState(rng_before[i]);
+                    return i;
+                }
+                const pct_expand_result &e = res[(size_t)(i - pos)];
+                const int32_t n_now = kdx_size(kdTree_);
+                int32_t best = e.near_idx;
+                if (best < 0) {                                       // the tree was empty at the snapshot
+                    if (n_now == 0) continue;                         // findNearstVertex finds nothing: the sample is skipped
+                    break;
+                }
+                const float qf[3] = { (float)sample[i].x, (float)sample[i].y, (float)sample[i].z };
+                double best_d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, best))->coord, qf);
+                bool conflict = false;
+                for (int32_t j = n0; j < n_now && !conflict; j++)     // a node added during this batch is strictly closer?
+                    conflict = kdDist2(((NodePtr)kdx_node_data(kdTree_, j))->coord, qf) < best_d2;
+                if (conflict) break;
+                NodePtr nearest = (NodePtr)kdx_node_data(kdTree_, best);
+                if (!nearest->valid) continue;                        // as the reference: skip the sample
+                n_inflate_++;
+                if (i > pos) n_spec_hit_++;
+                const Vec3 center(e.center[0], e.center[1], e.center[2]);
+                NodePtr fresh = new CorridorNode(center, (float)e.radius, (float)kInf, (float)getDis(center, end_pt));
+                kdres *pre = nullptr;
+                if (!(fresh->coord.z < z_l || fresh->radius < safety_margin_)) {
+                    const float cposf[3] = { (float)center.x, (float)center.y, (float)center.z };
+                    const float r = fresh->radius * 2.0f;
+                    pre = e.count >= 0 ? kdx_range_from_candidates(kdTree_, cposf, r, &ids[(size_t)(i - pos) * cap], e.count, n0)
+                                       : kd_nearest_rangef(kdTree_, cposf, r);
+                }
+                finishGrow(fresh, nearest, refine, pre);
+            }
+            if (i == K) break;
+            if (i == pos) { growWithSample(sample[i], refine); i++; }   // cannot happen (nothing is younger than the snapshot); never loop
+            else n_spec_miss_++;
+            pos = i;
+        }
+        return K;
+    }
+
+    int growBatchStaged(int K, bool refine)
     {
         const uint64_t epoch0 = sample_epoch_, kd_epoch0 = kd_epoch_;
         const int32_t n0 = kdx_size(kdTree_);
@@ -686,6 +771,7 @@ private:
                 const double update_radius = radiusSearch(ptr->coord);
                 const int ret = checkNodeUpdate(update_radius, ptr->radius);
                 ptr->radius = (float)update_radius;
+                syncNodeAux(ptr);
                 if (ret == -1) {
                     if (ptr->valid) { ptr->valid = false; invalidSet.push_back(ptr); clearBranchS(ptr); }
                     continue;
@@ -734,8 +820,9 @@ private:
     std::vector<Vec3> Path;
     std::vector<double> Radius;
     MinStdRand0 eng_;
-    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0;
-    int spec_k_ = 32;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
+    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0, n_launch_ = 0;
+    bool fused_ok_ = true;          // one-launch expansion batches (kdx_expand_batch); false = the three-stage form
+    int spec_k_ = 64;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
 };
 
 }  // namespace pct

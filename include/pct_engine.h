@@ -134,6 +134,18 @@ typedef struct pct_inflate_params {
 int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *pts, int64_t Q,
                       double *radius, uint32_t *idx, double *d2);
 
+/* ---- one RRT* iteration's three dependent queries in ONE launch (corridor_finder.cpp:385-410 genNewNode, :428-437
+ * findNearstVertex, :464 treeRewire's neighbourhood), for K samples at once: nearest tree node of the fp32-narrowed
+ * sample -> steer -> sphere inflation of the steered centre against `obstacles` -> tree nodes within 2*float(radius) of the
+ * centre.  `nodes` is the small (host-mapped) cloud of node coordinates; pct_cloud_small_aux() hands out its per-node
+ * planner data, 4 doubles per node {x, y, z, radius} (the node's fp64 centre and float radius, as the steer step reads
+ * them), which the caller keeps current with plain stores.  ids[k*cap_per_query ...] = candidate node numbers (unordered);
+ * out[k].count < 0 means -(count) hits of which only part were stored.  near_idx = -1 for an empty node set (centre = sample). */
+typedef struct pct_expand_result { double center[3]; double radius; int32_t near_idx; int32_t count; } pct_expand_result;
+int pct_cloud_small_aux(pct_cloud *nodes, double **host_aux);
+int pct_rrt_expand_batch(pct_cloud *nodes, pct_cloud *obstacles, const pct_inflate_params *p, const double *samples, int64_t K,
+                         int64_t cap_per_query, pct_expand_result *out, uint32_t *ids);
+
 typedef struct pct_bezier_traj {
     const double *polycoef;   /* nseg rows of row_stride doubles: [x_0..x_n, y_0..y_n, z_0..z_n], n = orders[seg] */
     int64_t row_stride;       /* 3 * (max_order + 1) */

@@ -145,6 +145,7 @@ public:
     int64_t size() const { return pct_cloud_size(cloud_); }
     bool empty() const { return cloud_empty_; }
     pct_cloud *handle() { return cloud_; }
+    const pct_inflate_params &params() const { return prm_; }
 
 private:
     static void check(int status, const char *what)

@@ -53,6 +53,11 @@ int pct_corridor_speculation_stats(pct_corridor *c, uint64_t *hit, uint64_t *mis
 {
     return guarded([&] { if (hit) *hit = c->impl->speculativeHits(); if (miss) *miss = c->impl->speculativeFallbacks(); });
 }
+int pct_corridor_set_fused_expansion(pct_corridor *c, int on) { return guarded([&] { c->impl->setFusedExpansion(on != 0); }); }
+int pct_corridor_expansion_launches(pct_corridor *c, uint64_t *launches)
+{
+    return guarded([&] { if (launches) *launches = c->impl->expansionLaunches(); });
+}
 int pct_corridor_set_input(pct_corridor *c, const void *points, int64_t n, int64_t stride_bytes, int build_index)
 {
     return guarded([&] { c->impl->setInput(points, n, stride_bytes, build_index != 0); });

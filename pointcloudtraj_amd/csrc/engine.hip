@@ -103,6 +103,9 @@ struct pct_cloud {
     ExpressOut *h_xout = nullptr, *d_xout = nullptr;
     double *h_xin = nullptr, *d_xin = nullptr, *h_xr = nullptr, *d_xr = nullptr;
     uint32_t *h_xids = nullptr, *d_xids = nullptr;
+    // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
+    double *h_aux = nullptr, *d_aux = nullptr;
+    ExpandOut *h_eout = nullptr, *d_eout = nullptr;
     unsigned char *d_stage = nullptr;
     size_t stage_bytes = 0;
     // grid
@@ -649,6 +652,8 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xin) (void)hipHostFree(c->h_xin);
     if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
+    if (c->h_aux) (void)hipHostFree(c->h_aux);
+    if (c->h_eout) (void)hipHostFree(c->h_eout);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
@@ -1189,6 +1194,45 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
     if (idx) HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
     if (d2) HIPCHK(hipMemcpyAsync(d2, c->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
+
+// ---- fused RRT* expansion step (kernels.hpp rrt_expand_kernel) ----------------------------------------------------------
+int pct_cloud_small_aux(pct_cloud *nodes, double **host_aux)
+{
+    if (!nodes || !host_aux) return fail(PCT_ERR_INVALID, "null argument");
+    if (!nodes->host_mapped) return fail(PCT_ERR_INVALID, "per-node planner data lives beside small (host-mapped) clouds only");
+    if (!nodes->h_aux) PCTCHK(mapped_alloc(&nodes->h_aux, &nodes->d_aux, (size_t)4 * (size_t)nodes->cap));
+    *host_aux = nodes->h_aux;
+    return PCT_OK;
+}
+
+int pct_rrt_expand_batch(pct_cloud *nodes, pct_cloud *obstacles, const pct_inflate_params *p, const double *samples, int64_t K,
+                         int64_t cap_per_query, pct_expand_result *out, uint32_t *ids)
+{
+    if (!nodes || !obstacles || !p || K < 0 || (K > 0 && (!samples || !out || !ids)) || cap_per_query <= 0) return fail(PCT_ERR_INVALID, "bad expand arguments");
+    if (K == 0) return PCT_OK;
+    if (K > kExpressMaxQ) return fail(PCT_ERR_INVALID, "at most %d samples per expansion launch", kExpressMaxQ);
+    if (!nodes->host_mapped || (nodes->count > 0 && !nodes->h_aux)) return fail(PCT_ERR_INVALID, "the node set must be a small cloud with per-node planner data (pct_cloud_small_aux)");
+    if (obstacles->count > 0 && !obstacles->has_grid) return fail(PCT_ERR_INVALID, "the obstacle cloud needs its cell index (pct_cloud_build_grid)");
+    if (!nodes->h_eout) PCTCHK(mapped_alloc(&nodes->h_eout, &nodes->d_eout, (size_t)kExpressMaxQ));
+    const uint32_t cap = (uint32_t)std::min<int64_t>(cap_per_query, kExpressIdsCap / K);
+    std::memcpy(nodes->h_xin, samples, sizeof(double) * 3 * K);
+    const double reach = p->max_radius + p->search_margin;       // only the radius is wanted: stop once everything unseen is beyond it
+    rrt_expand_kernel<<<(int)K, 256, 0, g_stream>>>(nodes->x, nodes->y, nodes->z, (uint32_t)nodes->count, nodes->d_aux, nodes->d_xin,
+                                                    obstacles->G, obstacles->sorted, obstacles->cell_start, obstacles->C,
+                                                    obstacles->count == 0 ? 1 : 0, to_dev(p), reach * reach, nodes->d_xids, cap, nodes->d_eout);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g_stream));
+    for (int64_t k = 0; k < K; k++) {
+        const ExpandOut &e = nodes->h_eout[k];
+        out[k].center[0] = e.cx; out[k].center[1] = e.cy; out[k].center[2] = e.cz;
+        out[k].radius = e.radius;
+        out[k].near_idx = e.near_idx == kNoIndex ? -1 : (int32_t)e.near_idx;
+        const int64_t got = std::min<int64_t>(e.count, cap);
+        out[k].count = e.count > cap ? -(int32_t)e.count : (int32_t)e.count;     // negative = list truncated: ask that range query alone
+        std::copy(nodes->h_xids + k * cap, nodes->h_xids + k * cap + got, ids + k * cap_per_query);
+    }
     return PCT_OK;
 }
 

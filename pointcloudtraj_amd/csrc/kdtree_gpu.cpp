@@ -50,6 +50,10 @@ struct kdtree {
     void (*destr)(void *) = nullptr;
     pct_cloud *cloud = nullptr;
     int64_t synced = 0;           // nodes [0, synced) are in HBM
+    // optional per-node planner data {x, y, z, radius} for the fused expansion step (kdx_set_node_aux / kdx_expand_batch):
+    // master copy here, mirrored into the cloud's host-mapped array
+    std::vector<double> aux;
+    double *aux_mapped = nullptr;
     int64_t count() const { return (int64_t)data.size(); }
 };
 
@@ -70,6 +74,7 @@ int sync_device(kdtree *t)
         pct_cloud_destroy(t->cloud);
         t->cloud = nullptr;
         t->synced = 0;
+        t->aux_mapped = nullptr;
     }
     if (!t->cloud) {
         int64_t cap = 1024;
@@ -84,6 +89,8 @@ int sync_device(kdtree *t)
         int st = (t->synced == 0) ? pct_cloud_upload_aos(t->cloud, t->posf.data(), n, 12)
                                   : pct_cloud_append_aos(t->cloud, t->posf.data() + 3 * t->synced, n - t->synced, 12);
         if (st != PCT_OK) { complain("cloud upload"); return -1; }
+        if (!t->aux.empty() && (t->aux_mapped || pct_cloud_small_aux(t->cloud, &t->aux_mapped) == PCT_OK))
+            std::memcpy(t->aux_mapped + 4 * t->synced, t->aux.data() + 4 * t->synced, sizeof(double) * 4 * (size_t)(n - t->synced));
         t->synced = n;
     }
     return 0;
@@ -167,7 +174,7 @@ struct kdtree *kd_create(int k)
 void kd_clear(struct kdtree *t)
 {
     run_destructors(t);
-    t->pos.clear(); t->posf.clear(); t->data.clear();
+    t->pos.clear(); t->posf.clear(); t->data.clear(); t->aux.clear();
     t->lo.clear(); t->hi.clear(); t->parent.clear(); t->axis.clear();
     t->synced = 0;
     if (t->cloud) pct_cloud_upload_aos(t->cloud, nullptr, 0, 12);
@@ -211,6 +218,7 @@ int kd_insert(struct kdtree *t, const double *p, void *data)
         t->pos.insert(t->pos.end(), p, p + 3);
         t->posf.insert(t->posf.end(), pf, pf + 3);
         t->data.push_back(data);
+        { const double a[4] = { p[0], p[1], p[2], 0.0 }; t->aux.insert(t->aux.end(), a, a + 4); }   // until kdx_set_node_aux says otherwise
         t->lo.push_back(NIL); t->hi.push_back(NIL); t->parent.push_back(par);
         t->axis.push_back((uint8_t)ax);
     } catch (const std::bad_alloc &) {
@@ -386,6 +394,26 @@ int kdx_range_candidates_batch(struct kdtree *t, const float *pos, const float *
         return 0;
     }
     for (int i = 0; i < k; i++) counts[i] = (int32_t)cnt[i];
+    return 0;
+}
+
+int kdx_set_node_aux(struct kdtree *t, int32_t node, const double aux[4])
+{
+    if (!t || node < 0 || node >= t->count() || !aux) return -1;
+    std::memcpy(&t->aux[4 * (size_t)node], aux, 4 * sizeof(double));
+    if (node < t->synced && t->aux_mapped) std::memcpy(t->aux_mapped + 4 * (size_t)node, aux, 4 * sizeof(double));   // plain store into mapped memory
+    return 0;
+}
+
+int kdx_expand_batch(struct kdtree *t, pct_cloud *obstacles, const pct_inflate_params *prm, const double *samples, int k, int cap_per_query,
+                     pct_expand_result *out, uint32_t *ids)
+{
+    if (!t || !obstacles || !prm || k < 0 || (k > 0 && (!samples || !out || !ids)) || cap_per_query <= 0) return -1;
+    if (k == 0) return 0;
+    if (t->count() > 65536) return -1;                      // the fused kernel serves host-mapped node sets
+    if (sync_device(t)) return -1;
+    if (t->count() > 0 && !t->aux_mapped) return -1;
+    if (pct_rrt_expand_batch(t->cloud, obstacles, prm, samples, k, cap_per_query, out, ids) != PCT_OK) return -1;
     return 0;
 }
 

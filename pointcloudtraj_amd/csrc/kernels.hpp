@@ -1592,27 +1592,16 @@ __device__ __forceinline__ void block_argmin256(double &d, uint32_t &i, double *
 // max_radius + search_margin (the radius is then max_radius whatever lies beyond); +inf = exact NN.
 // Same arithmetic and the same termination bound as coop_nn_search.
 // INFLATE = false: plain nearest neighbour of the (fp32-valued) points in qpts -- no early-out, no radius.
-template <bool INFLATE>
-__global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const float4 *__restrict__ pts0,
-                                                            const uint32_t *__restrict__ cs0, CoarseLevels C, InflateParams P,
-                                                            const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
-                                                            ExpressOut *__restrict__ out)
+// The block-wide search itself: nearest obstacle point of the fp32-narrowed (px, py, pz); every thread returns the winner.
+__device__ __forceinline__ void block_nn_search(const GridDesc &G0, const float4 *__restrict__ pts0, const uint32_t *__restrict__ cs0,
+                                                const CoarseLevels &C, double px, double py, double pz, double stop_d2,
+                                                double *s_d, uint32_t *s_i, double &bd, uint32_t &bi)
 {
-    __shared__ double s_d[4];
-    __shared__ uint32_t s_i[4];
-    const uint32_t slot = blockIdx.x, sub = threadIdx.x & (kCoop - 1), grp = threadIdx.x / kCoop;   // 32 groups
-    const double px = qpts[3 * slot], py = qpts[3 * slot + 1], pz = qpts[3 * slot + 2];
-    if (INFLATE) {
-        const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
-        if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {      // corridor_finder.cpp:115-116
-            if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
-            return;
-        }
-    }
+    const uint32_t sub = threadIdx.x & (kCoop - 1), grp = threadIdx.x / kCoop;   // 32 groups
     const float qxf = (float)px, qyf = (float)py, qzf = (float)pz;                    // searchPoint.x = search_Pt(0), :125-128
     const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
-    double bd = __builtin_huge_val();
-    uint32_t bi = kNoIndex;
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
     // steps: cube r=1 of the fine level, cube r=1 of every coarser level, then shells r=2,3,.. of the coarsest level
     for (int step = 0;; step++) {
         const int lvl = min(step, C.n);                       // 0 = fine, 1..C.n = coarse level lvl-1
@@ -1642,6 +1631,28 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const f
         if (bound == __builtin_huge_val()) break;             // the cube covers the whole box: every point has been seen
         if (bound > 0.0 && (bd <= bound * bound || bound * bound >= stop_d2)) break;
     }
+}
+
+template <bool INFLATE>
+__global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const float4 *__restrict__ pts0,
+                                                            const uint32_t *__restrict__ cs0, CoarseLevels C, InflateParams P,
+                                                            const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
+                                                            ExpressOut *__restrict__ out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const uint32_t slot = blockIdx.x;
+    const double px = qpts[3 * slot], py = qpts[3 * slot + 1], pz = qpts[3 * slot + 2];
+    if (INFLATE) {
+        const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
+        if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {      // corridor_finder.cpp:115-116
+            if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
+            return;
+        }
+    }
+    double bd;
+    uint32_t bi;
+    block_nn_search(G0, pts0, cs0, C, px, py, pz, stop_d2, s_d, s_i, bd, bi);
     if (threadIdx.x == 0) {
         if (INFLATE) {
             const double rr = sqrt(bd) - P.search_margin;
@@ -1649,6 +1660,87 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const f
         }
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
+    }
+}
+
+// One RRT* iteration's three dependent queries in ONE launch (corridor_finder.cpp:385-410 genNewNode, :428-437
+// findNearstVertex, :464 the treeRewire neighbourhood): a 256-thread block per sample
+//   A. nearest tree node of the fp32-narrowed sample (kd_nearestf semantics, lowest index on ties) over the node set,
+//   B. steer: centre = nearest + (sample - nearest) * (r_nearest / dist) when the sample lies outside the node's sphere,
+//      then the sphere inflation of that centre against the obstacle cloud (radiusSearch :113-133, early-out included),
+//   C. the nodes within 2 * float(radius) of the fp32-narrowed centre (candidates for kd_nearest_rangef).
+// Sequentially these are three launches + three host round trips (~45-70 us per sample); fused they are one (~20 us),
+// for one sample or for a speculative batch.  node_aux[4*i..] = {x, y, z, radius} of node i as the planner holds them
+// (fp64 coordinates, float radius widened), in host-mapped memory like the node coordinates themselves.
+struct ExpandOut { double cx, cy, cz, radius; uint32_t near_idx, count; };
+
+__global__ __launch_bounds__(256) void rrt_expand_kernel(const float *__restrict__ nx, const float *__restrict__ ny,
+                                                         const float *__restrict__ nz, uint32_t n_nodes,
+                                                         const double *__restrict__ node_aux, const double *__restrict__ samples,
+                                                         GridDesc G0, const float4 *__restrict__ pts0, const uint32_t *__restrict__ cs0,
+                                                         CoarseLevels C, int obstacles_empty, InflateParams P, double stop_d2,
+                                                         uint32_t *__restrict__ ids, uint32_t cap_per_query, ExpandOut *__restrict__ out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    __shared__ uint32_t s_n;
+    const uint32_t slot = blockIdx.x;
+    const double sx = samples[3 * slot], sy = samples[3 * slot + 1], sz = samples[3 * slot + 2];
+    if (threadIdx.x == 0) s_n = 0;
+    // ---- A: nearest node -------------------------------------------------------------------------------------------
+    double bd = __builtin_huge_val();
+    uint32_t near = kNoIndex;
+    {
+        const double qx = (double)(float)sx, qy = (double)(float)sy, qz = (double)(float)sz;
+        for (uint32_t i = threadIdx.x; i < n_nodes; i += 256) {
+            const double d2 = dist2((double)nx[i], (double)ny[i], (double)nz[i], qx, qy, qz);
+            if (d2 < bd) { bd = d2; near = i; }
+        }
+        block_argmin256(bd, near, s_d, s_i);
+    }
+    // ---- B: steer + inflate (every thread computes the same centre) ------------------------------------------------
+    double cx = sx, cy = sy, cz = sz;
+    if (near != kNoIndex) {
+        const double ax = node_aux[4 * near], ay = node_aux[4 * near + 1], az = node_aux[4 * near + 2], ar = node_aux[4 * near + 3];
+        const double dx = ax - sx, dy = ay - sy, dz = az - sz;
+        const double dis = sqrt(dx * dx + dy * dy + dz * dz);                    // getDis(nearest->coord, pt_sample)
+        if (dis > ar) {                                                          // :392-400
+            const double steer_dis = ar / dis;
+            cx = ax + (sx - ax) * steer_dis;
+            cy = ay + (sy - ay) * steer_dis;
+            cz = az + (sz - az) * steer_dis;
+        }
+    }
+    double radius;
+    {
+        const double dx = cx - P.sx, dy = cy - P.sy, dz = cz - P.sz;
+        if (obstacles_empty || sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {
+            radius = P.max_radius - P.search_margin;                             // :115-116
+        } else {
+            double od;
+            uint32_t oi;
+            block_nn_search(G0, pts0, cs0, C, cx, cy, cz, stop_d2, s_d, s_i, od, oi);
+            const double rr = sqrt(od) - P.search_margin;
+            radius = rr < P.max_radius ? rr : P.max_radius;
+        }
+    }
+    // ---- C: neighbourhood candidates ---------------------------------------------------------------------------------
+    {
+        const float rf = fmaxf((float)radius, 0.0f) * 2.0f;                      // range = radius * 2 on the float member (:462)
+        const double r = (double)rf, r2 = r * r;
+        const double qx = (double)(float)cx, qy = (double)(float)cy, qz = (double)(float)cz;
+        __syncthreads();                                                         // s_n = 0 is visible
+        for (uint32_t i = threadIdx.x; i < n_nodes; i += 256)
+            if (dist2((double)nx[i], (double)ny[i], (double)nz[i], qx, qy, qz) <= r2) {
+                const uint32_t pos = atomicAdd(&s_n, 1u);
+                if (pos < cap_per_query) ids[(size_t)slot * cap_per_query + pos] = i;
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[slot].cx = cx; out[slot].cy = cy; out[slot].cz = cz; out[slot].radius = radius;
+        out[slot].near_idx = near;
+        out[slot].count = s_n;
     }
 }
 

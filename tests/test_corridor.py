@@ -45,9 +45,10 @@ def test_oracle_corridor_c1(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("speculation", [1, 8, 64])
-def test_gpu_corridor_matches_oracle(oracle, speculation):
-    """speculation = samples per GPU round trip; every setting must give the one-by-one corridor"""
+@pytest.mark.parametrize("speculation,fused", [(1, True), (8, True), (64, True), (8, False), (64, False)])
+def test_gpu_corridor_matches_oracle(oracle, speculation, fused):
+    """speculation = samples per GPU round trip, fused = one launch per batch (nearest -> steer -> inflation -> range in one
+    kernel) or three; every setting must give the one-by-one corridor"""
     from pointcloudtraj_amd import corridor, engine
     engine.init(0)
     cloud1 = sensed_cloud(12.0)
@@ -55,10 +56,12 @@ def test_gpu_corridor_matches_oracle(oracle, speculation):
         want = run_scenario(oracle.PortCorridor(), cloud1, cloud2, expand=600, refine=200)
         finder = corridor.SafeRegionRrtStar(80000)
         finder.setSpeculation(speculation)
+        finder.setFusedExpansion(fused)
         got = run_scenario(finder, cloud1, cloud2, expand=600, refine=200)
         if speculation > 1:
             st = finder.speculationStats()
             assert st["replayed_from_batch"] > 100, st
+            assert (finder.expansionLaunches() > 0) == fused
         for k, ((pw, rw, sw), (pg, rg, sg)) in enumerate(zip(want, got)):
             assert sw["path_exists"] == sg["path_exists"] and sw["nodes"] == sg["nodes"], f"phase {k}: {sw} vs {sg}"
             assert np.array_equal(pw, pg), f"phase {k}: corridor centres differ"
