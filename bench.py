@@ -80,8 +80,9 @@ def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
     t_ing, t_cor, t_bez = [], [], []
     for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (workspaces, first launches)
         x0 = 0.1 * k
+        new_frame = frame_pts(k)                  # the sensor's output: produced outside the timed region
         t0 = time.perf_counter()
-        cloud.append(frame_pts(k))
+        cloud.append(new_frame)
         t1 = time.perf_counter()
         nodes = (synth.uniform_points(9, 64, -1.0, 1.0, offset=k * 64).astype(np.float64) * [8.0, 3.0, 1.0] + [x0 + 6.0, 0.0, 2.5])
         prm = E.inflate_params((x0, 0.0, 2.5), 30.0, 0.25, 1.5)
