@@ -186,6 +186,9 @@ int pct_plan_destroy(pct_plan *p);
  * pct_last_batch_ms: every kernel of the batch (binning, bounds, reduction included). ---------- */
 int pct_last_kernel_ms(pct_cloud *c, float *ms);
 int pct_last_batch_ms(pct_cloud *c, float *ms);
+/* dominant-kernel durations of the most recent batches (up to 64 are kept, oldest first): K batches can be queued back to
+ * back without a host sync and every launch's duration read afterwards */
+int pct_kernel_ms_history(pct_cloud *c, float *ms, int cap, int *n);
 /* algorithmic work of the last batch: points examined (sum over queries), cells examined */
 int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
 int pct_set_work_counters(pct_cloud *c, int enabled);

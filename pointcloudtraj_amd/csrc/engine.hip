@@ -149,7 +149,12 @@ struct pct_cloud {
     size_t coef_cap = 0, seg_cap = 0;
     // measurement
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the whole batch (all kernels of one query call)
-    hipEvent_t ev2 = nullptr, ev3 = nullptr;    // around the batch's dominant kernel only
+    hipEvent_t ev2 = nullptr, ev3 = nullptr;    // around the batch's dominant kernel only (aliases of the ring's current pair)
+    // the last kDomRing batches' dominant-kernel event pairs, so a caller can time K back-to-back batches without a host
+    // sync in between and read every launch's duration afterwards (bench.py's roofline figure)
+    static constexpr int kDomRing = 64;
+    hipEvent_t dom_ring[2 * kDomRing] = {};
+    uint64_t dom_seq = 0;                       // completed (begin + end) pairs
     bool ev_valid = false, dom_valid = false;
     WorkCounters *d_work = nullptr;
     bool count_work = false;
@@ -316,6 +321,9 @@ void dom_begin(pct_cloud *c, hipStream_t s)
 {
     c->dom_valid = false;
     if (c->capturing) return;
+    const int slot = (int)(c->dom_seq % pct_cloud::kDomRing);
+    c->ev2 = c->dom_ring[2 * slot];
+    c->ev3 = c->dom_ring[2 * slot + 1];
     if (hipEventRecord(c->ev2, s) == hipSuccess) c->dom_valid = true;
 }
 
@@ -323,6 +331,7 @@ void dom_end(pct_cloud *c, hipStream_t s)
 {
     if (c->capturing || !c->dom_valid) return;
     if (hipEventRecord(c->ev3, s) != hipSuccess) c->dom_valid = false;
+    else c->dom_seq++;
 }
 
 // streaming NN over the fp64 queries already in c->d_q64
@@ -621,8 +630,11 @@ static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out
         pct_cloud_destroy(c);
         return PCT_ERR_ALLOC;
     }
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->ev2) != hipSuccess ||
-        hipEventCreate(&c->ev3) != hipSuccess) {
+    bool ring_ok = true;
+    for (hipEvent_t &e : c->dom_ring) ring_ok = ring_ok && hipEventCreate(&e) == hipSuccess;
+    c->ev2 = c->dom_ring[0];
+    c->ev3 = c->dom_ring[1];
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess || !ring_ok) {
         pct_cloud_destroy(c);
         return fail(PCT_ERR_HIP, "hipEventCreate failed");
     }
@@ -666,8 +678,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev2) (void)hipEventDestroy(c->ev2);
-    if (c->ev3) (void)hipEventDestroy(c->ev3);
+    for (hipEvent_t e : c->dom_ring) if (e) (void)hipEventDestroy(e);
     delete c;
     return PCT_OK;
 }
@@ -1351,6 +1362,20 @@ int pct_last_kernel_ms(pct_cloud *c, float *ms)
     if (!c->dom_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
     HIPCHK(hipEventSynchronize(c->ev3));
     HIPCHK(hipEventElapsedTime(ms, c->ev2, c->ev3));
+    return PCT_OK;
+}
+
+int pct_kernel_ms_history(pct_cloud *c, float *ms, int cap, int *n)
+{
+    if (!c || !ms || !n || cap <= 0) return fail(PCT_ERR_INVALID, "bad arguments");
+    const uint64_t have = std::min<uint64_t>(c->dom_seq, pct_cloud::kDomRing);
+    const int take = (int)std::min<uint64_t>(have, (uint64_t)cap);
+    for (int i = 0; i < take; i++) {                       // oldest of the `take` most recent batches first
+        const int slot = (int)((c->dom_seq - take + i) % pct_cloud::kDomRing);
+        HIPCHK(hipEventSynchronize(c->dom_ring[2 * slot + 1]));
+        HIPCHK(hipEventElapsedTime(&ms[i], c->dom_ring[2 * slot], c->dom_ring[2 * slot + 1]));
+    }
+    *n = take;
     return PCT_OK;
 }
 
