@@ -106,6 +106,8 @@ def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
     return {"what": "C5: 5,000,000-point rolling cloud, +50,000 points per tick, 64 corridor-node inflations + 99-sample Bezier check per tick, host buffers",
             "ticks": ticks, "ms_per_tick_p50": pct(tot, 50), "ms_per_tick_p99": pct(tot, 99),
             "ingest_ms_p50": pct(t_ing, 50), "corridor_inflate_ms_p50": pct(t_cor, 50), "bezier_check_ms_p50": pct(t_bez, 50),
+            "worst_tick": {"index": int(np.argmax(tot)), "ingest_ms": float(np.asarray(t_ing)[np.argmax(tot)]),
+                           "corridor_inflate_ms": float(np.asarray(t_cor)[np.argmax(tot)]), "bezier_check_ms": float(np.asarray(t_bez)[np.argmax(tot)])},
             "budget_ms_at_20Hz": 50.0}
 
 
