@@ -151,6 +151,14 @@ def cpu_baseline(points_fn, n_points, queries, nq):
            "sample": f"{nq} of the batch's queries against a host kd-tree of {n_points} points "
                      f"(shuffled kd_insertf build {t_build:.1f} s, not included)",
            "build_s": round(t_build, 2)}
+    if hasattr(kd, "nearest_timed_mt"):
+        # the same tree shared read-only by every host core this process may use (the reference itself is single-threaded)
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        rep = max(1, min(8, threads // 2))                   # a few times the sample so each thread still runs ~0.1 s or more
+        qq = np.ascontiguousarray(np.concatenate([q] * rep))
+        secs_mt, idx_mt = kd.nearest_timed_mt(qq, threads)
+        if secs_mt > 0:
+            out["all_host_cores"] = {"value": len(qq) / secs_mt, "cores": threads, "same_ids_as_one_thread": bool(np.array_equal(idx_mt[:nq], idx))}
     return out, order[idx.astype(np.int64)], q
 
 

@@ -223,6 +223,14 @@ class RefKD:
         idx = np.empty(len(q), np.int32)
         return self.S.refshim_nearestf_timed(self.h, q, len(q), idx), idx
 
+    def nearest_timed_mt(self, q, threads: int):
+        """T threads on the shared read-only tree through kd_nearest (the *f variants are not re-entrant): (seconds, ids)"""
+        q = _f32c(q).reshape(-1, 3)
+        idx = np.empty(len(q), np.int32)
+        self.S.refshim_nearest_timed_mt.restype = C.c_double
+        self.S.refshim_nearest_timed_mt.argtypes = [C.c_void_p, _f32p, C.c_int64, _i32p, C.c_int]
+        return self.S.refshim_nearest_timed_mt(self.h, q, len(q), idx, int(threads)), idx
+
     def range_ids(self, q, r):
         q = _f32c(q).reshape(3)
         cap = max(self.n, 1)

@@ -79,3 +79,40 @@ int refshim_range_countf_batch(struct kdtree *t, const float *q, const float *ra
     }
     return 0;
 }
+
+/* T host threads sharing one read-only tree, queries partitioned in contiguous slices ("T threads with
+ * queries partitioned across threads on a shared read-only tree").  The *f query variants stage through a static buffer
+ * (kdtree.c:345-361) and are not re-entrant, so each thread widens its query itself and calls kd_nearest (doubles), which
+ * keeps no shared state.  Returns wall seconds for the whole batch. */
+#include <pthread.h>
+struct mt_job { struct kdtree *t; const float *q; int64_t begin, end; int32_t *idx; };
+
+static void *mt_worker(void *arg)
+{
+    struct mt_job *j = (struct mt_job *)arg;
+    for (int64_t i = j->begin; i < j->end; i++) {
+        const double p[3] = { j->q[3 * i], j->q[3 * i + 1], j->q[3 * i + 2] };
+        struct kdres *r = kd_nearest(j->t, p);
+        j->idx[i] = (int32_t)((intptr_t)kd_res_item_data(r) - 1);
+        kd_res_free(r);
+    }
+    return NULL;
+}
+
+double refshim_nearest_timed_mt(struct kdtree *t, const float *q, int64_t nq, int32_t *idx, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    struct mt_job job[256];
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int k = 0; k < threads; k++) {
+        job[k].t = t; job[k].q = q; job[k].idx = idx;
+        job[k].begin = nq * k / threads; job[k].end = nq * (k + 1) / threads;
+        if (pthread_create(&th[k], NULL, mt_worker, &job[k])) return -1.0;
+    }
+    for (int k = 0; k < threads; k++) pthread_join(th[k], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}
