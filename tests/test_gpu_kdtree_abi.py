@@ -132,3 +132,72 @@ def test_cpp_client_of_both_libraries():
     r = subprocess.run([build.DEMO_BIN], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all checks passed" in r.stdout
+
+
+@pytest.mark.parametrize("seed,n,lattice", [(1, 700, False), (2, 1500, True), (3, 70_000, False)])
+def test_differential_sequences_against_the_port(K, oracle, seed, n, lattice):
+    """Random op sequences (insert bursts, kd_nearestf, kd_nearest_rangef with assorted radii, kd_clear + refill) on the
+    drop-in and on the oracle port side by side: same range ITERATION order, same nearest distance, same nearest id
+    wherever the minimum is unique.  lattice=True puts the points on a 0.5 grid (ties, hits exactly at the radius, and
+    split-plane cases with fabs(dx) == range); n = 70 000 crosses from the host-mapped node set to the device-resident one."""
+    from pointcloudtraj_amd import synth
+    rng = np.random.default_rng(seed)
+    pts = synth.uniform_points(900 + seed, n, 0, 20)
+    if lattice:
+        pts = (np.round(pts * 2) / 2).astype(np.float32)
+    L = oracle.port_lib()
+    ot = L.okd_create(3)
+    t = K.KDTree()
+    state = {"base": 0, "n": 0}
+
+    def insert(k):
+        chunk = np.ascontiguousarray(pts[state["base"] + state["n"]: state["base"] + state["n"] + k])
+        t.insert(chunk)
+        assert L.okd_insertf_batch(ot, chunk, len(chunk)) == 0          # ids below are insertion indices, not payloads
+        state["n"] += len(chunk)
+
+    def check():
+        q = (rng.uniform(-1, 21, 3)).astype(np.float32)
+        if lattice and rng.random() < 0.5:
+            q = (np.round(q * 2) / 2).astype(np.float32)
+        qp = q.ctypes.data_as(C.POINTER(C.c_float))
+        ids, pos = t.nearest(q[None])
+        r = L.okd_nearestf(ot, qp)
+        want = L.okd_res_item_id(r)
+        L.okd_res_free(r)
+        cur = pts[state["base"]: state["base"] + state["n"]].astype(np.float64)
+        d = cur - q.astype(np.float64)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert d2[ids[0]] == d2[want] == d2.min()
+        if np.count_nonzero(d2 == d2.min()) == 1:
+            assert ids[0] == want
+        else:
+            assert ids[0] == int(np.argmin(d2))                      # documented tie rule: lowest insertion index
+        rad = float(rng.choice([0.5, 1.0, 1.5, 2.5, 0.0, 4.0]))
+        got = t.range_ids(q, rad)
+        rr = L.okd_nearest_rangef(ot, qp, C.c_float(rad))
+        exp = []
+        while not L.okd_res_end(rr):
+            exp.append(L.okd_res_item_id(rr))
+            L.okd_res_next(rr)
+        L.okd_res_free(rr)
+        assert list(got) == exp
+
+    big = n > 65536
+    insert(3)
+    check()
+    while state["n"] < (n if big else n // 2):
+        insert(int(rng.integers(1, 40)) if not big else 23_000)
+        for _ in range(2 if big else 1):
+            check()
+    if not big:                                                          # kd_clear, then a different set of points
+        t.L.kd_clear(t.h)
+        t.n = 0
+        L.okd_clear(ot)
+        state["base"] += state["n"]
+        state["n"] = 0
+        while state["base"] + state["n"] < n - 40:
+            insert(int(rng.integers(1, 40)))
+            check()
+    L.okd_free(ot)
+    t.close()
