@@ -611,6 +611,7 @@ struct GridDesc {
     double oxd, oyd, ozd, hd;  // fp64 face positions for the termination bound
     int gx, gy, gz;
     uint32_t ncells;
+    int octant_first;          // cooperative NN: try the 2x2x2 block on the query's side before the 3x3x3 cube
 };
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g)
@@ -1234,6 +1235,73 @@ __device__ __forceinline__ void coop_scan_cube_or_shell(const GridDesc &G, const
     }
 }
 
+// fp32 screening of NR x-runs by the 8 lanes of a group (min, runner-up, position), then the exact fp64 winner: if the
+// runner-up lies outside the fp32 error band the minimum IS the exact winner and is evaluated once in fp64, otherwise the
+// runs are rescanned in exact arithmetic.  All NR rows are requested before any is consumed (the kernel is bound by
+// dependent memory round trips: one for the bounds, one for the points).  Leaves (bd, bi) = (+inf, none) for empty runs.
+template <int NR>
+__device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts, const uint32_t (&rs)[NR], const uint32_t (&re)[NR],
+                                                 uint32_t sub, float qxf, float qyf, float qzf, double qx, double qy, double qz,
+                                                 double &bd, uint32_t &bi)
+{
+    float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+    uint32_t p1 = 0;
+    float4 P[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const uint32_t a = rs[k], b = re[k];
+        const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
+        P[k] = pts[min(a + sub, last)];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const uint32_t a = rs[k], b = re[k];
+        const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        d = (a + sub < b) ? d : __builtin_huge_valf();
+        const bool lt = d < m1;
+        m2 = lt ? m1 : fminf(m2, d);
+        p1 = lt ? a + sub : p1;
+        m1 = fminf(m1, d);
+    }
+#pragma unroll 1
+    for (int k = 0; k < NR; k++) {                                // rows longer than 8 points
+        const uint32_t b = re[k];
+        for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
+            const float4 Pp = pts[p];
+            const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool lt = d < m1;
+            m2 = lt ? m1 : fminf(m2, d);
+            p1 = lt ? p : p1;
+            m1 = fminf(m1, d);
+        }
+    }
+    // fold (smallest, runner-up, position) over the 8 lanes
+#pragma unroll
+    for (int off = 1; off < kCoop; off <<= 1) {
+        const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
+        const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
+        const bool lt = o1 < m1;
+        m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
+        p1 = lt ? op : p1;
+        m1 = fminf(m1, o1);
+    }
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
+    if (m1 < __builtin_huge_valf()) {
+        if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {            // unique within the fp32 error band: it is the exact winner
+            const float4 W = pts[p1];
+            bd = dist2((double)W.x, (double)W.y, (double)W.z, qx, qy, qz);
+            bi = __float_as_uint(W.w);
+        } else {                                                  // near-ties / duplicates: exact (d2, index) order decides
+#pragma unroll 1
+            for (int k = 0; k < NR; k++) coop_scan_exact(pts, rs[k], re[k], sub, qx, qy, qz, bd, bi);
+            coop_argmin8(bd, bi);
+        }
+    }
+}
+
 // The search itself, shared by the batch kernel and the low-latency inflation kernel: all 8 lanes of
 // a group call it with the same query and their own `sub`; every lane returns the same (bd, bi).
 template <bool COUNT>
@@ -1247,6 +1315,38 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
     const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
     bd = __builtin_huge_val();
     bi = kNoIndex;
+    if (G.octant_first) {   // ---- stage 0: the 2x2x2 block of cells on the query's side of its own cell = 4 x-runs ----
+        // About 27/8 fewer points and 9/4 fewer rows than the 3x3x3 cube; it decides the query whenever the best point found is
+        // closer than the block's nearest face that still has cells behind it (>= half a cell away by construction).  Which
+        // side is taken only affects how often that happens, never the result: the bound below is computed from the block
+        // actually scanned.
+        const float fx = (qxf - G.ox) * G.inv_h - (float)cx, fy = (qyf - G.oy) * G.inv_h - (float)cy, fz = (qzf - G.oz) * G.inv_h - (float)cz;
+        const int xa = max(fx < 0.5f ? cx - 1 : cx, 0), xb = min(fx < 0.5f ? cx : cx + 1, G.gx - 1);
+        const int ya = max(fy < 0.5f ? cy - 1 : cy, 0), yb = min(fy < 0.5f ? cy : cy + 1, G.gy - 1);
+        const int za = max(fz < 0.5f ? cz - 1 : cz, 0), zb = min(fz < 0.5f ? cz : cz + 1, G.gz - 1);
+        uint32_t rs[4], re[4];
+        {
+            const int ri = (int)sub & 3;                              // lanes 4..7 repeat lanes 0..3 (same addresses: no extra access)
+            const bool ok = !((ri >> 1) && zb == za) && !((ri & 1) && yb == ya);
+            const uint32_t row = cell_lin(G, 0, (ri & 1) ? yb : ya, (ri >> 1) ? zb : za);
+            const uint32_t a = cell_start[row + xa], b = cell_start[row + xb + 1];
+            const uint32_t my_s = a, my_e = ok ? b : a;
+            if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
+        }
+        coop_screen_rows<4>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+        double bound = __builtin_huge_val();
+        if (xa > 0) bound = fmin(bound, qx - (G.oxd + (double)xa * G.hd));
+        if (xb < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(xb + 1) * G.hd) - qx);
+        if (ya > 0) bound = fmin(bound, qy - (G.oyd + (double)ya * G.hd));
+        if (yb < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(yb + 1) * G.hd) - qy);
+        if (za > 0) bound = fmin(bound, qz - (G.ozd + (double)za * G.hd));
+        if (zb < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(zb + 1) * G.hd) - qz);
+        if (bound == __builtin_huge_val()) return;                    // the block covers the whole grid
+        bound -= G.hd * (1.0 / 256.0);                                // same slack as cube_bound (fp32 cell assignment)
+        if (bound > 0.0 && bd <= bound * bound) return;
+    }
     {   // ---- first cube: 3x3x3 cells = 9 x-runs ----
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
         // lane `sub` fetches row `sub`'s bounds, lane 0 also row 8
@@ -1277,62 +1377,7 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
         for (int k = 0; k < 8; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
         rs[8] = s8; re[8] = e8;
 
-        float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
-        uint32_t p1 = 0;
-        // all nine rows are requested before any is consumed (the kernel is bound by dependent
-        // memory round trips: one for the bounds, one for the points)
-        float4 P[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const uint32_t a = rs[k], b = re[k];
-            const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
-            P[k] = pts[min(a + sub, last)];
-        }
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const uint32_t a = rs[k], b = re[k];
-            const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
-            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            d = (a + sub < b) ? d : __builtin_huge_valf();
-            const bool lt = d < m1;
-            m2 = lt ? m1 : fminf(m2, d);
-            p1 = lt ? a + sub : p1;
-            m1 = fminf(m1, d);
-        }
-#pragma unroll 1
-        for (int k = 0; k < 9; k++) {                                // rows longer than 8 points
-            const uint32_t b = re[k];
-            for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
-                const float4 Pp = pts[p];
-                const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
-                const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                const bool lt = d < m1;
-                m2 = lt ? m1 : fminf(m2, d);
-                p1 = lt ? p : p1;
-                m1 = fminf(m1, d);
-            }
-        }
-        // fold (smallest, runner-up, position) over the 8 lanes
-#pragma unroll
-        for (int off = 1; off < kCoop; off <<= 1) {
-            const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
-            const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
-            const bool lt = o1 < m1;
-            m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
-            p1 = lt ? op : p1;
-            m1 = fminf(m1, o1);
-        }
-        if (m1 < __builtin_huge_valf()) {
-            if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {            // unique within the fp32 error band: it is the exact winner
-                const float4 P = pts[p1];
-                bd = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
-                bi = __float_as_uint(P.w);
-            } else {                                                  // near-ties / duplicates: exact (d2, index) order decides
-#pragma unroll 1
-                for (int k = 0; k < 9; k++) coop_scan_exact(pts, rs[k], re[k], sub, qx, qy, qz, bd, bi);
-                coop_argmin8(bd, bi);
-            }
-        }
+        coop_screen_rows<9>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
     }
     for (int r = 1;; r++) {
         if (r > 1) {   // ---- shell r (rare on dense clouds): rows walked in the same order by the whole group ----

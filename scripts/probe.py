@@ -86,3 +86,33 @@ if what == "sort":   # batch vs kernel-only time with the default grid (env knob
         med, mn = timeit(Q, E.ALGO_GRID, reps=20)
         kmed, kmn = timeit(Q, E.ALGO_GRID, reps=20, batch=False)
         print(f"sort probe fine={os.environ.get('PCT_SORT_FINE', '1')} shift={os.environ.get('PCT_BIN_SHIFT', '1')} Q={Q:8d} batch median={med*1e3:7.1f}us min={mn*1e3:7.1f}us  kernel median={kmed*1e3:7.1f}us min={kmn*1e3:7.1f}us", flush=True)
+
+if what == "octant":   # 2x2x2-block-first search vs cube-first, over cell sizes
+    for ppc in (1.0, 2.0, 3.0, 4.0, 6.0, 8.0):
+        for octant in (0, 1):
+            os.environ["PCT_GRID_PPC"] = str(ppc)
+            os.environ["PCT_OCTANT_FIRST"] = str(octant)
+            c.build_grid()
+            E.sync()
+            for Q in (1 << 20,):
+                med, mn = timeit(Q, E.ALGO_GRID, reps=15)
+                kmed, kmn = timeit(Q, E.ALGO_GRID, reps=15, batch=False)
+                c.set_work_counters(True)
+                c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, E.ALGO_GRID)
+                torch.cuda.synchronize()
+                w = [x / Q for x in c.last_work()]
+                c.set_work_counters(False)
+                print(f"octant={octant} ppc={ppc:3.1f} dims={c.grid_info()['dims']} Q={Q} batch median={med*1e3:7.1f}us kernel median={kmed*1e3:7.1f}us min={kmn*1e3:7.1f}us  points/query={w[0]:6.1f} runs/query={w[1]:5.2f}", flush=True)
+
+if what == "octant2":
+    os.environ["PCT_OCTANT_FIRST"] = "1"
+    for ppc in (5.0, 6.0, 7.0):
+        for shift in (0, 1):
+            os.environ["PCT_GRID_PPC"] = str(ppc)
+            os.environ["PCT_BIN_SHIFT"] = str(shift)
+            c.build_grid()
+            E.sync()
+            for Q in (1 << 16, 1 << 20):
+                med, mn = timeit(Q, E.ALGO_GRID, reps=15)
+                kmed, kmn = timeit(Q, E.ALGO_GRID, reps=15, batch=False)
+                print(f"octant=1 ppc={ppc:3.1f} shift={shift} dims={c.grid_info()['dims']} Q={Q} batch median={med*1e3:7.1f}us kernel median={kmed*1e3:7.1f}us min={kmn*1e3:7.1f}us", flush=True)
