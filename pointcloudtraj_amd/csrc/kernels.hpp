@@ -1239,35 +1239,41 @@ __device__ __forceinline__ void coop_scan_cube_or_shell(const GridDesc &G, const
 // runner-up lies outside the fp32 error band the minimum IS the exact winner and is evaluated once in fp64, otherwise the
 // runs are rescanned in exact arithmetic.  All NR rows are requested before any is consumed (the kernel is bound by
 // dependent memory round trips: one for the bounds, one for the points).  Leaves (bd, bi) = (+inf, none) for empty runs.
-template <int NR>
+template <int NR, int DEPTH>
 __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts, const uint32_t (&rs)[NR], const uint32_t (&re)[NR],
                                                  uint32_t sub, float qxf, float qyf, float qzf, double qx, double qy, double qz,
                                                  double &bd, uint32_t &bi)
 {
     float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
     uint32_t p1 = 0;
-    float4 P[NR];
+    // DEPTH points per lane and row (8 * DEPTH per row for the group) are requested up front
+    float4 P[NR][DEPTH];
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const uint32_t a = rs[k], b = re[k];
         const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
-        P[k] = pts[min(a + sub, last)];
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) P[k][j] = pts[min(a + sub + kCoop * j, last)];
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const uint32_t a = rs[k], b = re[k];
-        const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
-        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        d = (a + sub < b) ? d : __builtin_huge_valf();
-        const bool lt = d < m1;
-        m2 = lt ? m1 : fminf(m2, d);
-        p1 = lt ? a + sub : p1;
-        m1 = fminf(m1, d);
+#pragma unroll
+        for (int j = 0; j < DEPTH; j++) {
+            const uint32_t p = a + sub + kCoop * j;
+            const float dx = P[k][j].x - qxf, dy = P[k][j].y - qyf, dz = P[k][j].z - qzf;
+            float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            d = (p < b) ? d : __builtin_huge_valf();
+            const bool lt = d < m1;
+            m2 = lt ? m1 : fminf(m2, d);
+            p1 = lt ? p : p1;
+            m1 = fminf(m1, d);
+        }
     }
 #pragma unroll 1
-    for (int k = 0; k < NR; k++) {                                // rows longer than 8 points
+    for (int k = 0; k < NR; k++) {                                // rows longer than 8 * DEPTH points
         const uint32_t b = re[k];
-        for (uint32_t p = rs[k] + kCoop + sub; p < b; p += kCoop) {
+        for (uint32_t p = rs[k] + kCoop * DEPTH + sub; p < b; p += kCoop) {
             const float4 Pp = pts[p];
             const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
             const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -1335,7 +1341,7 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
 #pragma unroll
             for (int k = 0; k < 4; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
         }
-        coop_screen_rows<4>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+        coop_screen_rows<4, 2>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
         double bound = __builtin_huge_val();
         if (xa > 0) bound = fmin(bound, qx - (G.oxd + (double)xa * G.hd));
         if (xb < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(xb + 1) * G.hd) - qx);
@@ -1377,7 +1383,7 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
         for (int k = 0; k < 8; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
         rs[8] = s8; re[8] = e8;
 
-        coop_screen_rows<9>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+        coop_screen_rows<9, 1>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
     }
     for (int r = 1;; r++) {
         if (r > 1) {   // ---- shell r (rare on dense clouds): rows walked in the same order by the whole group ----
