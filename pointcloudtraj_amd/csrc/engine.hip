@@ -106,6 +106,7 @@ struct pct_cloud {
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
     double *h_aux = nullptr, *d_aux = nullptr;
     ExpandOut *h_eout = nullptr, *d_eout = nullptr;
+    double *h_bpos = nullptr, *d_bpos = nullptr;        // express Bezier check: sample positions
     unsigned char *d_stage = nullptr;
     size_t stage_bytes = 0;
     // grid
@@ -666,6 +667,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     if (c->h_aux) (void)hipHostFree(c->h_aux);
     if (c->h_eout) (void)hipHostFree(c->h_eout);
+    if (c->h_bpos) (void)hipHostFree(c->h_bpos);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
@@ -1262,8 +1264,62 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
     for (int i = 0; i < traj->nseg; i++)
         if (traj->orders[i] < 0 || traj->orders[i] > kMaxBezierOrder || 3 * (traj->orders[i] + 1) > traj->row_stride)
             return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
-    PCTCHK(pct_cloud_reserve_queries(c, cap));
     const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
+    if (c->has_grid && c->count > 0 && ncoef + (size_t)traj->nseg <= 3 * (size_t)kExpressMaxQ - 64) {
+        // express: the host enumerates the sample times (sim_planning_demo.cpp:729-771, the same sequential fp64 additions as
+        // bezier_samples_kernel), then ONE launch evaluates, inflates and searches every sample (bezier_block_kernel)
+        double *hd = c->h_xin;                                  // [coef | seg_time | sample_t]
+        uint32_t *hu = c->h_xids;                               // [orders | sample_seg]
+        std::memcpy(hd, traj->polycoef, sizeof(double) * ncoef);
+        std::memcpy(hd + ncoef, traj->seg_time, sizeof(double) * traj->nseg);
+        for (int i = 0; i < traj->nseg; i++) hu[i] = (uint32_t)traj->orders[i];
+        double *ht = hd + ncoef + traj->nseg;
+        uint32_t *hs = hu + traj->nseg;
+        const int64_t room = std::min<int64_t>({ cap, (int64_t)kExpressMaxQ, (int64_t)(3 * (size_t)kExpressMaxQ - ncoef - (size_t)traj->nseg) });
+        double t_s = t_start;
+        int first_seg;
+        for (first_seg = 0; first_seg < traj->nseg; ++first_seg) {
+            if (t_s > traj->seg_time[first_seg] && first_seg + 1 < traj->nseg) t_s -= traj->seg_time[first_seg];
+            else break;
+        }
+        int64_t n = 0;
+        double t_accu = 0.0;
+        for (int i = first_seg; i < traj->nseg; i++) {
+            const double T = traj->seg_time[i];
+            for (double t = (i == first_seg) ? t_s : 0.0; t < T; t += dt) {
+                t_accu += dt;
+                if (t_accu > stop_time) break;
+                if (n < room) { ht[n] = t; hs[n] = (uint32_t)i; }
+                n++;
+            }
+        }
+        const int64_t m = std::min<int64_t>(n, room);
+        const bool fits = n <= room || room == cap;             // more samples than one express launch holds: staged path below
+        if (fits && m > 0) {
+            if (!c->h_bpos) PCTCHK(mapped_alloc(&c->h_bpos, &c->d_bpos, (size_t)3 * kExpressMaxQ));
+            const double reach = p->max_radius + p->search_margin;
+            const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
+            bezier_block_kernel<<<(int)m, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, (int)traj->row_stride,
+                                                               c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg, c->d_xin + ncoef + traj->nseg,
+                                                               stop_d2, (uint32_t)c->index_base, c->d_xout, c->d_bpos);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(g_stream));
+        }
+        if (fits) {
+            int64_t fh = -1;
+            for (int64_t i = 0; i < m; i++) {
+                if (fh < 0 && c->h_xout[i].radius < 0.0) fh = i;
+                if (radius) radius[i] = c->h_xout[i].radius;
+                if (d2) d2[i] = c->h_xout[i].d2;
+                if (idx) idx[i] = c->h_xout[i].idx;
+            }
+            if (pos && m) std::memcpy(pos, c->h_bpos, sizeof(double) * 3 * m);
+            *nsamples = n;
+            *first_hit = fh;
+            return PCT_OK;
+        }
+    }
+    PCTCHK(pct_cloud_reserve_queries(c, cap));
     if (ncoef > c->coef_cap) { dev_free(c->d_coef); c->coef_cap = 0; PCTCHK(dev_alloc(&c->d_coef, ncoef)); c->coef_cap = ncoef; }
     if ((size_t)traj->nseg > c->seg_cap) {
         dev_free(c->d_segtime); dev_free(c->d_orders); c->seg_cap = 0;

@@ -1858,6 +1858,58 @@ __global__ __launch_bounds__(256) void bezier_samples_kernel(BezierDesc B, doubl
     }
 }
 
+// Low-latency form of the whole check on an indexed cloud: ONE launch, a 256-thread block per sample.  The host enumerates
+// the sample times (the same sequential fp64 additions as above: IEEE adds are the same on both sides) and hands (segment, t)
+// per sample; the block evaluates getPosFromBezier with one thread per Bernstein term (two pow calls each, the terms then
+// summed by one thread in the reference's j order), applies the inflation early-out and runs the block-wide cell search.
+// Arguments and results live in host-mapped memory; the host picks the first sample with a negative radius.
+__global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const float4 *__restrict__ pts0, const uint32_t *__restrict__ cs0,
+                                                           CoarseLevels C, InflateParams P, const double *__restrict__ coef, int row_stride,
+                                                           const double *__restrict__ seg_time, const uint32_t *__restrict__ orders,
+                                                           const uint32_t *__restrict__ sample_seg, const double *__restrict__ sample_t,
+                                                           double stop_d2, uint32_t index_base, ExpressOut *__restrict__ out,
+                                                           double *__restrict__ pos_out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    __shared__ double s_term[3 * (kMaxBezierOrder + 1)];
+    __shared__ double s_pos[3];
+    const uint32_t slot = blockIdx.x;
+    const int seg = (int)sample_seg[slot];
+    const int order = (int)orders[seg], m = order + 1;
+    const double T = seg_time[seg];
+    const double u = sample_t[slot] / T;
+    if ((int)threadIdx.x < 3 * m) {
+        const int d = (int)threadIdx.x / m, j = (int)threadIdx.x % m;
+        double b = 1.0;                                            // bezier_base.cpp:33-48 binomials as exact doubles
+        for (int i = 1; i <= j; i++) b = floor(b * (double)(order - i + 1) / (double)i + 0.5);
+        s_term[d * m + j] = b * coef[(size_t)seg * row_stride + d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (int j = 0; j < m; j++) acc += s_term[threadIdx.x * m + j];
+        s_pos[threadIdx.x] = acc * T;
+        pos_out[3 * slot + threadIdx.x] = acc * T;
+    }
+    __syncthreads();
+    const double px = s_pos[0], py = s_pos[1], pz = s_pos[2];
+    const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
+    if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {          // corridor_finder.cpp:115-116
+        if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
+        return;
+    }
+    double bd;
+    uint32_t bi;
+    block_nn_search(G0, pts0, cs0, C, px, py, pz, stop_d2, s_d, s_i, bd, bi);
+    if (threadIdx.x == 0) {
+        const double rr = sqrt(bd) - P.search_margin;
+        out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        out[slot].d2 = bd;
+    }
+}
+
 // first sample with negative radius (checkTrajPtCol, corridor_finder.cpp:412-416); -1 if none
 __global__ __launch_bounds__(256) void first_hit_kernel(const double *__restrict__ radius, const int *__restrict__ nsamples,
                                                         int cap, long long *__restrict__ first_hit)

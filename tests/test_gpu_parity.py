@@ -520,3 +520,22 @@ def test_full_size_properties_c4_sharded_on_one_card(E, oracle):
     s = P[:, 0] * P[:, 0]; s = s + P[:, 1] * P[:, 1]; s = s + P[:, 2] * P[:, 2]
     assert np.array_equal(s, best_d)
     whole.close()
+
+
+@pytest.mark.gpu
+def test_bezier_check_express_and_staged_paths_agree(E):
+    """The one-launch check (indexed cloud, <= 1024 samples), its fall-back for longer sample lists, and the brute-force path of
+    an un-indexed cloud must enumerate the same samples and report the same first hit, radii and distances."""
+    g = load_golden("bezier_check.npz")
+    plain = make_cloud(E, g["points"], grid=False)
+    indexed = make_cloud(E, g["points"], grid=True)
+    prm = E.inflate_params(g["start"], float(g["sample_range"]), float(g["search_margin"]), float(g["max_radius"]))
+    for case, dt, cap in ((5, 0.02, 4096), (5, 0.002, 4096), (6, 0.001, 4096), (0, 0.02, 50), (8, 0.004, 4096)):
+        coef = g[f"case{case}_polycoef"]
+        a = plain.bezier_check(prm, coef, g["seg_time"], g["orders"], float(g[f"case{case}_t_start"]), 3.0, dt=dt, cap=cap)
+        b = indexed.bezier_check(prm, coef, g["seg_time"], g["orders"], float(g[f"case{case}_t_start"]), 3.0, dt=dt, cap=cap)
+        assert a["n"] == b["n"] and a["first_hit"] == b["first_hit"], (case, dt, a["n"], b["n"], a["first_hit"], b["first_hit"])
+        assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["d2"], b["d2"]) and np.array_equal(a["idx"], b["idx"])
+        assert np.array_equal(a["radius"], b["radius"])
+    plain.close()
+    indexed.close()
