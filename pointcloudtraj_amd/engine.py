@@ -324,8 +324,8 @@ class NNPlan:
         return idx, d2
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().pct_plan_destroy(self._h)
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:      # _lib is None during interpreter shutdown
+            _lib.pct_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     __del__ = close

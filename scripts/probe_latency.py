@@ -30,3 +30,13 @@ print("kd_nearestf on a 1000-node tree: %.1f / %.1f us" % lat(kdq))
 def kdr():
     r = L.kd_nearest_rangef(t.h, qq, C.c_float(1.5)); L.kd_res_free(r)
 print("kd_nearest_rangef(1.5) on a 1000-node tree: %.1f / %.1f us" % lat(kdr))
+# the planner's checkSafeTrajectory (99 samples over a 2 s horizon) on the indexed cloud: one launch; and the fused RRT* step
+orders = np.int32([6, 6, 6]); seg_time = np.float64([1.0, 1.0, 1.0])
+coef = np.zeros((3, 21))
+for sgm in range(3):
+    for d in range(3):
+        for j in range(7):
+            coef[sgm, d * 7 + j] = (40.0 + 4.0 * (sgm + j / 6.0) + (0.3 if d == 1 else 0.0))
+print("bezier_check 99 samples (indexed cloud, one launch): %.1f / %.1f us" % lat(lambda: c.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128)))
+c2 = E.Cloud(len(pts)); c2.set_input(pts[:5_000_000])
+print("bezier_check 99 samples (un-indexed 5 M cloud, brute force, staged): %.1f / %.1f us" % lat(lambda: c2.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128), 50))
