@@ -383,7 +383,7 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         const int nb = ceil_div(Q, (int64_t)per_block);
         qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, d_q, (uint32_t)Q, per_block, c->d_qbin, total1, fill1);
         qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, total1, fill1, start1, c->d_sortkey, c->d_sorttmp);
-        qsort_fine_kernel<<<kSortBuckets, 256, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, c->d_perm, c->d_qsorted);
+        qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, c->d_perm, c->d_qsorted);
         HIPCHK(hipGetLastError());
         *perm_out = c->d_perm;
         return PCT_OK;

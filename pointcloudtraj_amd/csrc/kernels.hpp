@@ -912,27 +912,29 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
     }
 }
 
-// one block per level-1 bucket: counting sort by the low 10 key bits, then emit perm / qsorted
-__global__ __launch_bounds__(256) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
-                                                         const uint32_t *__restrict__ start1, uint32_t *__restrict__ total1,
-                                                         uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
+// one block per level-1 bucket: counting sort by the low 10 key bits, then emit perm / qsorted.  1024 threads: a bucket holds
+// Q / (occupied level-1 buckets) records (~5000 at 1 M queries over 211 buckets), and the three passes are latency-bound
+// (same-box A/B: 256 threads 0.2068 ms per step, 1024 threads 0.2008; spreading the keys over more level-1 buckets instead,
+// key >> 8 = 844 buckets, gained nothing)
+constexpr int kFineThreads = 1024;
+__global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
+                                                                  const uint32_t *__restrict__ start1, uint32_t *__restrict__ total1,
+                                                                  uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
 {
+    static_assert(kSortBuckets == kFineThreads, "one histogram entry per thread");
     __shared__ uint32_t h[kSortBuckets];
-    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_wave[kFineThreads / 64];
     const uint32_t s = start1[blockIdx.x], e = start1[blockIdx.x + 1];
     if (threadIdx.x == 0) total1[blockIdx.x] = 0;      // its last reader (scatter1) has finished: ready for the next batch
     if (s == e) return;
-    for (int i = threadIdx.x; i < kSortBuckets; i += 256) h[i] = 0;
+    h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = s + threadIdx.x; i < e; i += 256) atomicAdd(&h[tmp_key[i] & 1023u], 1u);
+    for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) atomicAdd(&h[tmp_key[i] & 1023u], 1u);
     __syncthreads();
-    // exclusive scan of h[1024] in place: 4 entries per thread
+    // exclusive scan of h[1024] in place: one entry per thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = h[threadIdx.x * 4 + k];
-    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-    uint32_t inc = tsum;
+    const uint32_t v = h[threadIdx.x];
+    uint32_t inc = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = (uint32_t)__shfl_up((int)inc, off, kWave);
@@ -940,12 +942,11 @@ __global__ __launch_bounds__(256) void qsort_fine_kernel(const uint32_t *__restr
     }
     if (lane == 63) s_wave[wave] = inc;
     __syncthreads();
-    uint32_t run = inc - tsum;
+    uint32_t run = inc - v;
     for (int w = 0; w < wave; w++) run += s_wave[w];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { h[threadIdx.x * 4 + k] = run; run += v[k]; }
+    h[threadIdx.x] = run;
     __syncthreads();
-    for (uint32_t i = s + threadIdx.x; i < e; i += 256) {
+    for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) {
         const float4 rec = tmp_rec[i];
         const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & 1023u], 1u);
         perm[pos] = __float_as_uint(rec.w);
