@@ -126,8 +126,12 @@ class ShardedCloud:
         s = torch.cuda.current_stream().cuda_stream
         self.cloud.nn_device(q.data_ptr(), Q, idx32.data_ptr(), d2.data_ptr(), s, algo)
         if self.world > 1 and self.n_total < 2 ** 31 - 1:
-            # indices < 2^31 are exchanged as int32 (the u32 bit pattern is non-negative; NO_INDEX -> INT32_MAX)
+            # indices < 2^31 are exchanged as int32 (the u32 bit pattern is non-negative; NO_INDEX -> INT32_MAX).  A non-empty
+            # shard answers every query, so the fix-up kernels are only queued for an empty one (they would sit on the
+            # compute stream, in front of the next batch)
             i32 = idx32[:Q]
+            if self.end > self.begin:
+                return d2[:Q], i32
             return d2[:Q], torch.where(i32 < 0, torch.full_like(i32, torch.iinfo(torch.int32).max), i32)
         # u32 -> int64 (NO_INDEX stays recognisable through d2 == +inf)
         return d2[:Q], idx32[:Q].to(torch.int64) & 0xFFFFFFFF
