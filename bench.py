@@ -154,7 +154,7 @@ def cpu_baseline(points_fn, n_points, queries, nq):
     if hasattr(kd, "nearest_timed_mt"):
         # the same tree shared read-only by every host core this process may use (the reference itself is single-threaded)
         threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        rep = max(1, min(8, threads // 2))                   # a few times the sample so each thread still runs ~0.1 s or more
+        rep = max(1, min(64, threads // 4))                  # a few thousand queries per thread, so thread start-up does not dominate
         qq = np.ascontiguousarray(np.concatenate([q] * rep))
         secs_mt, idx_mt = kd.nearest_timed_mt(qq, threads)
         if secs_mt > 0:
