@@ -52,6 +52,8 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int kMaxParts = 2048;       // streaming kernel: at most 8 blocks of 256 per CU
+constexpr int64_t kPartQueries = 16384;   // the partial buffers hold this many queries (400 MB); a 1 M-query reservation used to
+                                          // take 26 GB of HBM for them
 constexpr int kBezierCapMax = 4096;
 
 template <typename T>
@@ -136,8 +138,9 @@ struct pct_cloud {
     double *d_q64 = nullptr, *d_r2 = nullptr, *d_d2 = nullptr, *d_radius = nullptr, *d_pts64 = nullptr;
     uint32_t *d_idx = nullptr, *d_count = nullptr, *d_bound = nullptr;
     unsigned char *d_skip = nullptr;
-    double *d_part_d2 = nullptr;
-    uint32_t *d_part_idx = nullptr;
+    double *d_part_d2 = nullptr;      // per-(query, block) partial minima of the streaming kernels: part_q x kMaxParts entries;
+    uint32_t *d_part_idx = nullptr;   // larger batches go through them in slices of part_q queries
+    int64_t part_q = 0;
     // order-preserving crop (lidar): tile counts and the compacted {index, d2, x, y, z} of the last crop
     uint32_t *crop_tile = nullptr, *crop_idx = nullptr;
     double *crop_d2 = nullptr;
@@ -284,9 +287,9 @@ int stream_blocks(int64_t n)
 }
 
 template <int QT>
-void launch_nn_stream(pct_cloud *c, int blocks, int q0, int qcount, hipStream_t s)
+void launch_nn_stream(pct_cloud *c, const double *d_q64, int blocks, int q0, int qcount, hipStream_t s)
 {
-    nn_stream_kernel<QT><<<blocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_q64, q0, qcount, c->d_part_d2,
+    nn_stream_kernel<QT><<<blocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, q0, qcount, c->d_part_d2,
                                                  c->d_part_idx, blocks);
 }
 
@@ -335,9 +338,12 @@ void dom_end(pct_cloud *c, hipStream_t s)
     else c->dom_seq++;
 }
 
-// streaming NN over the fp64 queries already in c->d_q64
-int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+// streaming NN over the fp64 queries already in c->d_q64: one slice of at most c->part_q queries starting at qoff
+int nn_stream_q64_slice(pct_cloud *c, int64_t qoff, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
 {
+    const double *d_q64 = c->d_q64 + 3 * qoff;
+    d_idx += qoff;
+    d_d2 += qoff;
     const int blocks = stream_blocks(c->count);
     begin_timing(c, s);
     dom_begin(c, s);
@@ -345,10 +351,10 @@ int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStr
         const int qt = pick_tile(Q - q0);
         const int qcount = (int)std::min<int64_t>(qt, Q - q0);
         switch (qt) {
-        case 8: launch_nn_stream<8>(c, blocks, (int)q0, qcount, s); break;
-        case 4: launch_nn_stream<4>(c, blocks, (int)q0, qcount, s); break;
-        case 2: launch_nn_stream<2>(c, blocks, (int)q0, qcount, s); break;
-        default: launch_nn_stream<1>(c, blocks, (int)q0, qcount, s); break;
+        case 8: launch_nn_stream<8>(c, d_q64, blocks, (int)q0, qcount, s); break;
+        case 4: launch_nn_stream<4>(c, d_q64, blocks, (int)q0, qcount, s); break;
+        case 2: launch_nn_stream<2>(c, d_q64, blocks, (int)q0, qcount, s); break;
+        default: launch_nn_stream<1>(c, d_q64, blocks, (int)q0, qcount, s); break;
         }
         q0 += qcount;
     }
@@ -357,6 +363,13 @@ int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStr
     end_timing(c, s);
     HIPCHK(hipGetLastError());
     c->host_work = true;                    // the streaming kernel examines every point for every query
+    c->host_points = (uint64_t)Q * (uint64_t)c->count;
+    return PCT_OK;
+}
+
+int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+{
+    for (int64_t off = 0; off < Q; off += c->part_q) PCTCHK(nn_stream_q64_slice(c, off, std::min<int64_t>(c->part_q, Q - off), d_idx, d_d2, s));
     c->host_points = (uint64_t)Q * (uint64_t)c->count;
     return PCT_OK;
 }
@@ -406,8 +419,13 @@ constexpr uint32_t kChunkGroupsMax = 3072;   // 3 * 3072 * 16 B = 144 KiB of the
 
 // Default brute-force path: packed-fp32 filter + exact fp64 recheck over LDS-staged chunks
 // (kernels.hpp).  d_qf: the fp32 queries; c->d_q64 must already hold their widened copies.
-int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
 {
+    d_qf += 3 * qoff;
+    d_idx += qoff;
+    d_d2 += qoff;
+    const double *d_q64 = c->d_q64 + 3 * qoff;
+    uint32_t *d_bound = c->d_bound + qoff;
     static bool attr_set = false;
     if (!attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -427,25 +445,33 @@ int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_i
                                 : 1u;
     const int64_t schunks = std::max<int64_t>(1, (ngroups + 256ll * stride - 1) / (256ll * stride));
     const int sblocks = (int)((schunks + kSampleGroups - 1) / kSampleGroups);
-    const int64_t part_cap = c->qcap * kMaxParts;          // entries in d_part_d2 / d_part_idx
+    const int64_t part_cap = c->part_q * kMaxParts;        // entries in d_part_d2 / d_part_idx
     begin_timing(c, s);
     // the sample partials borrow d_part_idx (u32 and float have the same size; [Q][sblocks], sblocks <= kMaxParts);
     // bound_reduce_kernel consumes them before the filter pass overwrites the buffer
     nn_sample_bounds_kernel<<<sblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, stride, d_qf, (int)Q,
                                                     reinterpret_cast<float *>(c->d_part_idx), sblocks);
-    bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, c->d_bound);
+    bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, d_bound);
     const int64_t qb_max = std::max<int64_t>(kTileQ, part_cap / nblocks / kTileQ * kTileQ);
     for (int64_t qbase = 0; qbase < Q; qbase += qb_max) {
         const int qb = (int)std::min<int64_t>(qb_max, Q - qbase);
         if (qbase == 0) dom_begin(c, s);
-        nn_tile_filter_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, c->d_q64,
-                                                                                       c->d_bound, (int)qbase, qb, c->d_part_d2, c->d_part_idx, nblocks);
+        nn_tile_filter_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, d_q64,
+                                                                                       d_bound, (int)qbase, qb, c->d_part_d2, c->d_part_idx, nblocks);
         if (qbase == 0) dom_end(c, s);
         nn_reduce_partials_kernel<<<qb, 256, 0, s>>>(c->d_part_d2, c->d_part_idx, nblocks, (uint32_t)c->index_base, d_idx + qbase, d_d2 + qbase);
     }
     end_timing(c, s);
     HIPCHK(hipGetLastError());
     c->host_work = true;
+    c->host_points = (uint64_t)Q * (uint64_t)c->count;
+    return PCT_OK;
+}
+
+int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
+{
+    for (int64_t off = 0; off < Q; off += c->part_q)
+        PCTCHK(nn_stream_filtered_slice(c, d_qf, off, std::min<int64_t>(c->part_q, Q - off), d_idx, d_d2, s));
     c->host_points = (uint64_t)Q * (uint64_t)c->count;
     return PCT_OK;
 }
@@ -792,8 +818,9 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
         PCTCHK(dev_alloc(&c->d_sort1, 3 * kSortBuckets + 8));
         HIPCHK(hipMemset(c->d_sort1, 0, sizeof(uint32_t) * (3 * kSortBuckets + 8)));   // the sort keeps total1 zero between batches
     }
-    PCTCHK(dev_alloc(&c->d_part_d2, (size_t)q * kMaxParts));
-    PCTCHK(dev_alloc(&c->d_part_idx, (size_t)q * kMaxParts));
+    c->part_q = std::min<int64_t>(q, kPartQueries);
+    PCTCHK(dev_alloc(&c->d_part_d2, (size_t)c->part_q * kMaxParts));
+    PCTCHK(dev_alloc(&c->d_part_idx, (size_t)c->part_q * kMaxParts));
     c->qcap = q;
     return PCT_OK;
 }

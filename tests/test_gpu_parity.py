@@ -539,3 +539,23 @@ def test_bezier_check_express_and_staged_paths_agree(E):
         assert np.array_equal(a["radius"], b["radius"])
     plain.close()
     indexed.close()
+
+
+@pytest.mark.gpu
+def test_streaming_batches_larger_than_the_partial_buffers(E, oracle):
+    """The brute-force kernels keep per-(query, block) partial minima for 16 384 queries at a time; larger batches go through
+    in slices.  40 000 queries (two full slices and a ragged one): filter path, all-fp64 path and the cell-pruned path agree
+    bit for bit, and a sample equals the exhaustive oracle."""
+    pts = synth.uniform_points(71, 60_000, 0, 40)
+    q = synth.uniform_points(72, 40_000, -2, 42)
+    c = make_cloud(E, pts)
+    i1, d1 = c.nn(q, E.ALGO_STREAM)
+    i2, d2 = c.nn(q, E.ALGO_STREAM_EXACT)
+    c.build_grid()
+    i3, d3 = c.nn(q, E.ALGO_GRID)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    assert np.array_equal(i1, i3) and np.array_equal(d1, d3)
+    pick = np.r_[0:64, 16380:16390, 32760:32776, 39990:40000]
+    bi, bd = oracle.brute_nearest(pts, q[pick])
+    assert np.array_equal(d1[pick], bd) and np.array_equal(i1[pick].astype(np.int64), bi.astype(np.int64))
+    c.close()
