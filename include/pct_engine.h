@@ -186,6 +186,10 @@ int pct_plan_destroy(pct_plan *p);
  * pct_last_batch_ms: every kernel of the batch (binning, bounds, reduction included). ---------- */
 int pct_last_kernel_ms(pct_cloud *c, float *ms);
 int pct_last_batch_ms(pct_cloud *c, float *ms);
+/* which HIP events the batch entry points record: 0 = none, 1 = around the batch's dominant kernel (default; what
+ * pct_last_kernel_ms / pct_kernel_ms_history read), 2 = also around the whole batch (pct_last_batch_ms).  An event pair
+ * costs 5-9 us per batch. */
+int pct_set_timing(pct_cloud *c, int level);
 /* dominant-kernel durations of the most recent batches (up to 64 are kept, oldest first): K batches can be queued back to
  * back without a host sync and every launch's duration read afterwards */
 int pct_kernel_ms_history(pct_cloud *c, float *ms, int cap, int *n);

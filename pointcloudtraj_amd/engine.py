@@ -96,6 +96,7 @@ def lib():
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        L.pct_set_timing.argtypes = [vp, C.c_int]
         L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_set_work_counters.argtypes = [vp, i32]
         _lib = L
@@ -280,6 +281,10 @@ class Cloud:
 
     def radius_count_device(self, q_ptr: int, r_ptr: int, Q: int, cnt_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
         _chk(lib().pct_radius_count_batch_dev(self._h, algo, q_ptr, r_ptr, int(Q), cnt_ptr, stream))
+
+    def set_timing(self, level: int):
+        """0 = no events, 1 = dominant kernel only (default), 2 = + whole batch (needed by last_batch_ms)"""
+        _chk(lib().pct_set_timing(self._h, int(level)))
 
     def kernel_ms_history(self, n: int = 64):
         """dominant-kernel durations (ms) of the last <= n batches, oldest first (HIP events on the launch stream)"""

@@ -21,6 +21,7 @@ qh = synth.uniform_points(5, 1 << 20, 0, 100)
 q = torch.from_numpy(qh).cuda()
 Qmax = len(qh)
 c.reserve_queries(Qmax)
+c.set_timing(2)
 idx = torch.empty(Qmax, dtype=torch.int32, device="cuda")
 d2 = torch.empty(Qmax, dtype=torch.float64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
