@@ -538,10 +538,20 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
         PCTCHK(bin_queries(c, d_q, Q, s, &perm));
-        if (c->count_work)
+        static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
+        dom_begin(c, s);
+        if (coop) {   // 8 lanes per query (default)
+            const int blocks = ceil_div(Q, 256 / kCoop);
+            const float4 *qs = perm ? c->d_qsorted : nullptr;
+            if (c->count_work)
+                count_grid_coop_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, qs, d_count, c->d_work);
+            else
+                count_grid_coop_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, qs, d_count, c->d_work);
+        } else if (c->count_work)
             count_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, perm, d_count, c->d_work);
         else
             count_grid_kernel<false><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, d_r, (uint32_t)Q, perm, d_count, c->d_work);
+        dom_end(c, s);
         end_timing(c, s);
         HIPCHK(hipGetLastError());
         return PCT_OK;

@@ -1436,8 +1436,90 @@ __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const flo
     }
 }
 
-// radius count through the grid: every cell row overlapping the ball's bounding box
-// (one extra cell of margin for the fp32 cell assignment) is scanned.
+// Cooperative radius count: 8 lanes per query, the rows of the ball's bounding box taken four at a time -- four lanes fetch
+// the four run bounds at once, then every lane has two 16-byte loads per row in flight (16 points per row for the group)
+// before the first compare; longer rows finish in a tail loop.  Every distance is the exact fp64 one (kdtree.c:273,
+// d2 <= r*r inclusive).  The box is [q - r - pad, q + r + pad] with pad = h/100: a point within r of q can only sit in a
+// cell of that range, because the fp32 cell assignment errs by < 4e-4 cells (same argument as cube_bound's h/256 slack).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void count_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
+                                                              const uint32_t *__restrict__ cell_start,
+                                                              const float *__restrict__ q, const float *__restrict__ rad, uint32_t Q,
+                                                              const float4 *__restrict__ qsorted, uint32_t *__restrict__ count,
+                                                              WorkCounters *__restrict__ work)
+{
+    const uint32_t sub = threadIdx.x & (kCoop - 1);
+    const uint32_t bslot = qsorted ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
+    const uint32_t slot = bslot * (256 / kCoop) + (threadIdx.x / kCoop);
+    uint32_t npts = 0, nruns = 0;
+    if (slot < Q) {                                   // uniform within a group of 8 lanes
+        uint32_t t = slot;
+        float qxf, qyf, qzf;
+        if (qsorted) {
+            const float4 R = qsorted[slot];
+            qxf = R.x; qyf = R.y; qzf = R.z; t = __float_as_uint(R.w);
+        } else {
+            qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
+        }
+        const float rf = rad[t];
+        const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+        const double r2 = (double)rf * (double)rf;
+        const float pad = fabsf(rf) + 0.01f * (1.0f / G.inv_h);   // r enters only squared (kdtree.c:273)
+        const int x0 = cell_coord(qxf - pad, G.ox, G.inv_h, G.gx), x1 = cell_coord(qxf + pad, G.ox, G.inv_h, G.gx);
+        const int y0 = cell_coord(qyf - pad, G.oy, G.inv_h, G.gy), y1 = cell_coord(qyf + pad, G.oy, G.inv_h, G.gy);
+        const int z0 = cell_coord(qzf - pad, G.oz, G.inv_h, G.gz), z1 = cell_coord(qzf + pad, G.oz, G.inv_h, G.gz);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        uint32_t c = 0;
+        for (int base = 0; base < nrows; base += 4) {
+            uint32_t rs[4], re[4];
+            {
+                const int k = base + ((int)sub & 3);              // lanes 4..7 repeat lanes 0..3 (same addresses)
+                const bool ok = k < nrows;
+                const uint32_t row = ok ? cell_lin(G, 0, y0 + k % ny, z0 + k / ny) : 0u;
+                const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
+                const uint32_t my_s = a, my_e = ok ? b : a;
+                if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) { rs[j] = (uint32_t)__shfl((int)my_s, j, kCoop); re[j] = (uint32_t)__shfl((int)my_e, j, kCoop); }
+            }
+            float4 P[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t last = re[j] > rs[j] ? re[j] - 1 : 0u;
+                P[j][0] = pts[min(rs[j] + sub, last)];
+                P[j][1] = pts[min(rs[j] + sub + kCoop, last)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int d = 0; d < 2; d++) {
+                    const bool in = rs[j] + sub + kCoop * d < re[j];
+                    c += (in && dist2((double)P[j][d].x, (double)P[j][d].y, (double)P[j][d].z, qx, qy, qz) <= r2) ? 1u : 0u;
+                }
+            }
+#pragma unroll 1
+            for (int j = 0; j < 4; j++)
+                for (uint32_t p = rs[j] + 2 * kCoop + sub; p < re[j]; p += kCoop) {
+                    const float4 Pp = pts[p];
+                    c += dist2((double)Pp.x, (double)Pp.y, (double)Pp.z, qx, qy, qz) <= r2 ? 1u : 0u;
+                }
+        }
+#pragma unroll
+        for (int off = 1; off < kCoop; off <<= 1) c += (uint32_t)__shfl_xor((int)c, off, kWave);
+        if (sub == 0) count[t] = c;
+    }
+    if (COUNT) {
+        unsigned long long a = npts, b = nruns;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a += (unsigned long long)__shfl_xor((long long)a, off, kWave);
+            b += (unsigned long long)__shfl_xor((long long)b, off, kWave);
+        }
+        if ((threadIdx.x & 63) == 0) { WorkCounters *w = work + (blockIdx.x & (kWorkSlots - 1)); atomicAdd(&w->points, a); atomicAdd(&w->cells, b); }
+    }
+}
+
+// radius count through the grid, one lane per query (PCT_GRID_COOP=0): every cell row overlapping the ball's bounding box.
 template <bool COUNT>
 __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                          const uint32_t *__restrict__ cell_start,
@@ -1458,9 +1540,7 @@ __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float
             int x0 = cell_coord(qxf - pad, G.ox, G.inv_h, G.gx), x1 = cell_coord(qxf + pad, G.ox, G.inv_h, G.gx);
             int y0 = cell_coord(qyf - pad, G.oy, G.inv_h, G.gy), y1 = cell_coord(qyf + pad, G.oy, G.inv_h, G.gy);
             int z0 = cell_coord(qzf - pad, G.oz, G.inv_h, G.gz), z1 = cell_coord(qzf + pad, G.oz, G.inv_h, G.gz);
-            x0 = max(x0 - 1, 0); x1 = min(x1 + 1, G.gx - 1);
-            y0 = max(y0 - 1, 0); y1 = min(y1 + 1, G.gy - 1);
-            z0 = max(z0 - 1, 0); z1 = min(z1 + 1, G.gz - 1);
+            // (no extra cell of margin: pad's h/100 already covers the < 4e-4-cell error of the fp32 cell assignment)
             for (int zz = z0; zz <= z1; zz++)
                 for (int yy = y0; yy <= y1; yy++) {
                     const uint32_t row = cell_lin(G, 0, yy, zz);

@@ -117,3 +117,27 @@ if what == "octant2":
                 med, mn = timeit(Q, E.ALGO_GRID, reps=15)
                 kmed, kmn = timeit(Q, E.ALGO_GRID, reps=15, batch=False)
                 print(f"octant=1 ppc={ppc:3.1f} shift={shift} dims={c.grid_info()['dims']} Q={Q} batch median={med*1e3:7.1f}us kernel median={kmed*1e3:7.1f}us min={kmn*1e3:7.1f}us", flush=True)
+
+if what == "count":   # radius count through the grid and brute force
+    c.build_grid()
+    E.sync()
+    cnt = torch.empty(Qmax, dtype=torch.int32, device="cuda")
+    for rad in (0.5, 1.0, 2.0):
+        r = torch.full((Qmax,), rad, dtype=torch.float32, device="cuda")
+        for Q in (4096, 1 << 16, 1 << 20):
+            for _ in range(2):
+                c.radius_count_device(q.data_ptr(), r.data_ptr(), Q, cnt.data_ptr(), s, E.ALGO_GRID)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5):
+                c.radius_count_device(q.data_ptr(), r.data_ptr(), Q, cnt.data_ptr(), s, E.ALGO_GRID)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+            print(f"count grid r={rad} Q={Q:8d}: {dt*1e3:8.3f} ms  {Q/dt:.3e} q/s  mean count {float(cnt[:Q].float().mean()):.1f}", flush=True)
+    r = torch.full((Qmax,), 1.0, dtype=torch.float32, device="cuda")
+    for Q in (64, 4096):
+        for _ in range(2):
+            c.radius_count_device(q.data_ptr(), r.data_ptr(), Q, cnt.data_ptr(), s, E.ALGO_STREAM)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3):
+            c.radius_count_device(q.data_ptr(), r.data_ptr(), Q, cnt.data_ptr(), s, E.ALGO_STREAM)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+        print(f"count stream r=1.0 Q={Q:8d}: {dt*1e3:8.3f} ms  {Q/dt:.3e} q/s  pairs/s {Q*N/dt:.3e}", flush=True)
