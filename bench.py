@@ -312,6 +312,22 @@ def main():
         out["corridor_probe"] = {"what": "pct_inflate_batch, 200 seeds (seed 4), search_margin 0.25, max_radius 1.5, host buffers",
                                  "ms_per_pass_median": float(np.median(ts)), "ms_per_pass_p99": float(np.percentile(ts, 99))}
 
+    if a.stream_probe and world == 1 and sc.cloud.has_grid:
+        # radius count through the index (kd_nearest_range + kd_res_size semantics, d2 <= r*r), same cloud and query batch
+        r1 = torch.full((Q,), 1.0, dtype=torch.float32, device=sc.device)
+        ts = []
+        for k in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cnt = sc.radius_count(q, r1)
+            torch.cuda.synchronize()
+            if k:
+                ts.append(time.perf_counter() - t1)
+        out["radius_count_probe"] = {"what": f"pct_radius_count_batch_dev, {Q} queries, r = 1.0, cell-pruned cooperative kernel",
+                                     "ms_per_batch": 1e3 * float(np.median(ts)), "queries_per_s": Q / float(np.median(ts)),
+                                     "mean_count": float(cnt.double().mean().item())}
+        del r1, cnt
+
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
         # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
