@@ -328,6 +328,27 @@ def main():
                                      "mean_count": float(cnt.double().mean().item())}
         del r1, cnt
 
+    if a.stream_probe and world == 1:
+        # config C2: 1 M uniform points (seed 1), 4096 queries (seed 2), host buffers in and out (PCIe + launch latency included)
+        p2 = synth.uniform_points(1, 1_000_000, 0.0, 100.0)
+        q2 = synth.uniform_points(2, 4096, 0.0, 100.0)
+        with E.Cloud(len(p2)) as c2:
+            c2.set_input(p2)
+            def med(fn, n=7):
+                ts = []
+                for k in range(n):
+                    t1 = time.perf_counter()
+                    fn()
+                    if k:
+                        ts.append(1e3 * (time.perf_counter() - t1))
+                return float(np.median(ts))
+            brute_ms = med(lambda: c2.nn(q2, E.ALGO_STREAM))
+            build_ms = med(lambda: c2.build_grid(), 4)
+            grid_ms = med(lambda: c2.nn(q2, E.ALGO_GRID))
+        out["c2_probe"] = {"what": "C2: 1,000,000 uniform points, 4096 NN queries, host buffers (pct_nn_batch_algo)",
+                           "brute_force_ms": brute_ms, "pair_evals_per_s": 4096 * 1e6 / (brute_ms * 1e-3),
+                           "index_build_ms": build_ms, "indexed_ms": grid_ms, "indexed_queries_per_s": 4096 / (grid_ms * 1e-3)}
+
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
         # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
