@@ -141,6 +141,8 @@ struct pct_cloud {
     double *d_part_d2 = nullptr;      // per-(query, block) partial minima of the streaming kernels: part_q x kMaxParts entries;
     uint32_t *d_part_idx = nullptr;   // larger batches go through them in slices of part_q queries
     int64_t part_q = 0;
+    uint32_t *d_cand_count = nullptr, *d_cand_idx = nullptr;   // candidate lists of the brute-force filter: part_q x kCandCap
+    double *d_cand_d2 = nullptr;
     // order-preserving crop (lidar): tile counts and the compacted {index, d2, x, y, z} of the last crop
     uint32_t *crop_tile = nullptr, *crop_idx = nullptr;
     double *crop_d2 = nullptr;
@@ -453,6 +455,26 @@ int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int6
     nn_sample_bounds_kernel<<<sblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, stride, d_qf, (int)Q,
                                                     reinterpret_cast<float *>(c->d_part_idx), sblocks);
     bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, d_bound);
+    static const bool candidates = [] { const char *e = std::getenv("PCT_TILE_CANDIDATES"); return e ? std::atoi(e) != 0 : true; }();
+    if (candidates) {       // survivors of the bound go to per-query candidate lists: no per-tile block reductions, no partial arrays
+        static bool attr2 = false;
+        if (!attr2) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_candidates_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(3 * kChunkGroupsMax * sizeof(float4))));
+            attr2 = true;
+        }
+        dom_begin(c, s);
+        nn_tile_candidates_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, d_q64, d_bound,
+                                                                                           (int)Q, c->d_cand_count, c->d_cand_d2, c->d_cand_idx);
+        dom_end(c, s);
+        nn_reduce_candidates_kernel<<<(int)Q, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, c->d_cand_count, c->d_cand_d2, c->d_cand_idx,
+                                                           (uint32_t)c->index_base, d_idx, d_d2);
+        end_timing(c, s);
+        HIPCHK(hipGetLastError());
+        c->host_work = true;
+        c->host_points = (uint64_t)Q * (uint64_t)c->count;
+        return PCT_OK;
+    }
     const int64_t qb_max = std::max<int64_t>(kTileQ, part_cap / nblocks / kTileQ * kTileQ);
     for (int64_t qbase = 0; qbase < Q; qbase += qb_max) {
         const int qb = (int)std::min<int64_t>(qb_max, Q - qbase);
@@ -711,7 +733,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
     dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
@@ -807,7 +829,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     const int64_t q = std::max<int64_t>(Q, 256);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
     c->qcap = 0;
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
     PCTCHK(dev_alloc(&c->d_r, q));
@@ -832,6 +854,10 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     c->part_q = std::min<int64_t>(q, kPartQueries);
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)c->part_q * kMaxParts));
     PCTCHK(dev_alloc(&c->d_part_idx, (size_t)c->part_q * kMaxParts));
+    PCTCHK(dev_alloc(&c->d_cand_count, (size_t)c->part_q));
+    PCTCHK(dev_alloc(&c->d_cand_d2, (size_t)c->part_q * kCandCap));
+    PCTCHK(dev_alloc(&c->d_cand_idx, (size_t)c->part_q * kCandCap));
+    HIPCHK(hipMemset(c->d_cand_count, 0, sizeof(uint32_t) * (size_t)c->part_q));     // the reduce kernel keeps it zero between slices
     c->qcap = q;
     return PCT_OK;
 }

@@ -352,6 +352,126 @@ __global__ __launch_bounds__(256) void nn_tile_filter_kernel(const float *__rest
     }
 }
 
+// Candidate-list form of the filter (default).  The kernel above keeps a running (d2, index) per lane and query and folds it
+// per block and per tile of 8 queries -- two __syncthreads, a wave argmin and 8 partial writes for every tile, which at
+// 4096 queries is 512 block reductions per block and, for clouds under a few million points, most of the run time; it also
+// needs the [query][block] partial arrays and a second kernel to fold them.  But survivors of the fp32 bound are rare (about
+// as many points as the sample stride lie closer than the closest SAMPLED point), so here a lane that holds one evaluates it
+// exactly and appends (d2, index) to its query's candidate list in global memory; nothing else leaves the tile loop.
+// nn_reduce_candidates_kernel then folds each list by (d2, index).  A list that overflows kCandCap entries (exact ties in
+// bulk: duplicate points, lattice clouds seen from a lattice point) is resolved by that kernel with an exact scan of the
+// whole cloud for that query -- slow, rare, and still exact.
+constexpr uint32_t kCandCap = 256;
+
+__global__ __launch_bounds__(256) void nn_tile_candidates_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                 const float *__restrict__ z, uint32_t n, uint32_t chunk_groups,
+                                                                 const float *__restrict__ qf, const double *__restrict__ q64,
+                                                                 const uint32_t *__restrict__ bound_bits, int Q,
+                                                                 uint32_t *__restrict__ cand_count, double *__restrict__ cand_d2,
+                                                                 uint32_t *__restrict__ cand_idx)
+{
+    extern __shared__ float4 s_pts[];                 // [3][chunk_groups]
+    const uint32_t ngroups = n >> 2;
+    const uint32_t g0 = blockIdx.x * chunk_groups;
+    const uint32_t ng = min(chunk_groups, ngroups > g0 ? ngroups - g0 : 0u);
+    float4 *sx = s_pts, *sy = s_pts + chunk_groups, *sz = s_pts + 2 * chunk_groups;
+    for (uint32_t i = threadIdx.x; i < ng; i += 256) {
+        sx[i] = reinterpret_cast<const float4 *>(x)[g0 + i];
+        sy[i] = reinterpret_cast<const float4 *>(y)[g0 + i];
+        sz[i] = reinterpret_cast<const float4 *>(z)[g0 + i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const bool tail_owner = (blockIdx.x == gridDim.x - 1) && threadIdx.x < (n & 3u);   // n % 4 leftover points
+
+    for (int q0 = 0; q0 < Q; q0 += kTileQ) {
+        const int qcount = min(kTileQ, Q - q0);
+        float qx[kTileQ], qy[kTileQ], qz[kTileQ], thr[kTileQ];
+#pragma unroll
+        for (int j = 0; j < kTileQ; j++) {
+            const int qi = q0 + (j < qcount ? j : qcount - 1);
+            qx[j] = qf[3 * qi]; qy[j] = qf[3 * qi + 1]; qz[j] = qf[3 * qi + 2];
+            thr[j] = __uint_as_float(bound_bits[qi]) * (1.0f + 0x1p-19f) + 0x1p-90f;   // FLT_MAX bound -> +inf: everything is a candidate
+        }
+        for (uint32_t i = threadIdx.x; i < ng; i += 256) {
+            const float4 X = sx[i], Y = sy[i], Z = sz[i];
+            const PointGroup pg = make_group(X, Y, Z);
+            unsigned long long hit = 0ull;
+#pragma unroll
+            for (int j = 0; j < kTileQ; j++) hit |= __builtin_amdgcn_ballot_w64(group_min_d32(pg, qx[j], qy[j], qz[j]) <= thr[j]);
+            if (hit != 0ull) {                                 // wave-uniform: some lane holds a possible winner for some query
+                if ((hit >> lane) & 1ull) {
+                    const float xs[4] = { X.x, X.y, X.z, X.w }, ys[4] = { Y.x, Y.y, Y.z, Y.w }, zs[4] = { Z.x, Z.y, Z.z, Z.w };
+#pragma unroll 1
+                    for (int j = 0; j < qcount; j++) {
+                        if (!(group_min_d32(pg, qx[j], qy[j], qz[j]) <= thr[j])) continue;
+                        const int qi = q0 + j;
+                        const double Qx = q64[3 * qi], Qy = q64[3 * qi + 1], Qz = q64[3 * qi + 2];
+                        double bd = __builtin_huge_val();
+                        uint32_t bi = kNoIndex;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const double d2 = dist2((double)xs[k], (double)ys[k], (double)zs[k], Qx, Qy, Qz);
+                            if (d2 < bd) { bd = d2; bi = 4u * (g0 + i) + (uint32_t)k; }       // ids grow with k: lowest index on ties
+                        }
+                        const uint32_t slot = atomicAdd(&cand_count[qi], 1u);
+                        if (slot < kCandCap) { cand_d2[(size_t)qi * kCandCap + slot] = bd; cand_idx[(size_t)qi * kCandCap + slot] = bi; }
+                    }
+                }
+            }
+        }
+        if (tail_owner) {
+            const uint32_t id = 4u * ngroups + threadIdx.x;
+            const double px = (double)x[id], py = (double)y[id], pz = (double)z[id];
+            for (int j = 0; j < qcount; j++) {
+                const int qi = q0 + j;
+                const double d2 = dist2(px, py, pz, q64[3 * qi], q64[3 * qi + 1], q64[3 * qi + 2]);
+                // the true nearest neighbour is never farther than the nearest SAMPLED point, whose fp32 distance is the bound
+                if (d2 <= (double)thr[j] * (1.0 + 0x1p-18) + 1e-300) {
+                    const uint32_t slot = atomicAdd(&cand_count[qi], 1u);
+                    if (slot < kCandCap) { cand_d2[(size_t)qi * kCandCap + slot] = d2; cand_idx[(size_t)qi * kCandCap + slot] = id; }
+                }
+            }
+        }
+    }
+}
+
+// one 256-thread block per query: fold its candidate list by (d2, index); re-zero the counter for the next slice.  An
+// overflowed list falls back to an exact scan of the whole cloud by this block.
+__global__ __launch_bounds__(256) void nn_reduce_candidates_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                                   const float *__restrict__ z, uint32_t n,
+                                                                   const double *__restrict__ q64, uint32_t *__restrict__ cand_count,
+                                                                   const double *__restrict__ cand_d2, const uint32_t *__restrict__ cand_idx,
+                                                                   uint32_t index_base, uint32_t *__restrict__ out_idx,
+                                                                   double *__restrict__ out_d2)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const int q = blockIdx.x;
+    const uint32_t count = cand_count[q];
+    double d = __builtin_huge_val();
+    uint32_t i = kNoIndex;
+    if (count <= kCandCap) {
+        if (threadIdx.x < count) { d = cand_d2[(size_t)q * kCandCap + threadIdx.x]; i = cand_idx[(size_t)q * kCandCap + threadIdx.x]; }
+    } else {
+        const double qx = q64[3 * q], qy = q64[3 * q + 1], qz = q64[3 * q + 2];
+        for (uint32_t p = threadIdx.x; p < n; p += 256) {
+            const double d2 = dist2((double)x[p], (double)y[p], (double)z[p], qx, qy, qz);
+            if (d2 < d) { d = d2; i = p; }                    // ids grow within a thread
+        }
+    }
+    wave_argmin(d, i);
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (better(s_d[w], s_i[w], d, i)) { d = s_d[w]; i = s_i[w]; }
+        out_idx[q] = (i == kNoIndex) ? kNoIndex : i + index_base;
+        out_d2[q] = d;
+        cand_count[q] = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
