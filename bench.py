@@ -294,7 +294,7 @@ def main():
         # (b) brute force at config C2's batch size: LDS-tiled packed-fp32 filter + exact fp64 recheck
         qn = 4096
         ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 5)
-        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + nn_tile_filter_kernel + nn_reduce_partials_kernel",
+        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + nn_tile_candidates_kernel + nn_reduce_candidates_kernel",
                                     "queries": qn, "kernel_ms": ms, "queries_per_s": qn / (ms * 1e-3),
                                     "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
                                     "flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}

@@ -452,8 +452,17 @@ int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int6
     begin_timing(c, s);
     // the sample partials borrow d_part_idx (u32 and float have the same size; [Q][sblocks], sblocks <= kMaxParts);
     // bound_reduce_kernel consumes them before the filter pass overwrites the buffer
-    nn_sample_bounds_kernel<<<sblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, stride, d_qf, (int)Q,
-                                                    reinterpret_cast<float *>(c->d_part_idx), sblocks);
+    // slices of the batch in grid.y until ~2048 blocks are in flight (the kernels' tile loops are sequential)
+    const auto slices_for = [&](int point_blocks, int *qslice) {
+        const int tiles = (int)((Q + kTileQ - 1) / kTileQ);
+        int slices = std::max(1, std::min(tiles, (2048 + point_blocks - 1) / point_blocks));
+        *qslice = ((tiles + slices - 1) / slices) * kTileQ;
+        return (int)((Q + *qslice - 1) / *qslice);
+    };
+    int sq = 0;
+    const int sslices = slices_for(sblocks, &sq);
+    nn_sample_bounds_kernel<<<dim3(sblocks, sslices), 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, stride, d_qf, (int)Q, sq,
+                                                                   reinterpret_cast<float *>(c->d_part_idx), sblocks);
     bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, d_bound);
     static const bool candidates = [] { const char *e = std::getenv("PCT_TILE_CANDIDATES"); return e ? std::atoi(e) != 0 : true; }();
     if (candidates) {       // survivors of the bound go to per-query candidate lists: no per-tile block reductions, no partial arrays
@@ -464,8 +473,11 @@ int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int6
             attr2 = true;
         }
         dom_begin(c, s);
-        nn_tile_candidates_kernel<<<nblocks, 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf, d_q64, d_bound,
-                                                                                           (int)Q, c->d_cand_count, c->d_cand_d2, c->d_cand_idx);
+        int cq = 0;
+        const int cslices = slices_for(nblocks, &cq);
+        nn_tile_candidates_kernel<<<dim3(nblocks, cslices), 256, 3 * (size_t)chunk * sizeof(float4), s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, d_qf,
+                                                                                                          d_q64, d_bound, (int)Q, cq, c->d_cand_count,
+                                                                                                          c->d_cand_d2, c->d_cand_idx);
         dom_end(c, s);
         nn_reduce_candidates_kernel<<<(int)Q, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, c->d_cand_count, c->d_cand_d2, c->d_cand_idx,
                                                            (uint32_t)c->index_base, d_idx, d_d2);

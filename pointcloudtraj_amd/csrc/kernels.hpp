@@ -208,7 +208,7 @@ __device__ __forceinline__ float block_min_transposed(const float (&m)[QT], floa
 // covers the whole query batch: bound_part[q * nsblocks + b].
 __global__ __launch_bounds__(256) void nn_sample_bounds_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                const float *__restrict__ z, uint32_t n, uint32_t sample_stride,
-                                                               const float *__restrict__ qf, int Q,
+                                                               const float *__restrict__ qf, int Q, int qslice,
                                                                float *__restrict__ bound_part, int nsblocks)
 {
     __shared__ float s_red[kTileQ * 256];
@@ -222,8 +222,11 @@ __global__ __launch_bounds__(256) void nn_sample_bounds_kernel(const float *__re
         if (g < ngroups) pg[c] = make_group(reinterpret_cast<const float4 *>(x)[g], reinterpret_cast<const float4 *>(y)[g],
                                             reinterpret_cast<const float4 *>(z)[g]);
     }
-    for (int q0 = 0; q0 < Q; q0 += kTileQ) {
-        const int qcount = min(kTileQ, Q - q0);
+    // blockIdx.y takes a slice of the batch (a multiple of kTileQ queries): small clouds have few point blocks, and the
+    // tile loop below is sequential, so the batch is what fills the chip (4096 queries on 1 M points: 0.8 -> 0.1 ms)
+    const int q_end = min(Q, ((int)blockIdx.y + 1) * qslice);
+    for (int q0 = (int)blockIdx.y * qslice; q0 < q_end; q0 += kTileQ) {
+        const int qcount = min(kTileQ, q_end - q0);
         float m[kTileQ];
 #pragma unroll
         for (int j = 0; j < kTileQ; j++) {
@@ -366,7 +369,7 @@ constexpr uint32_t kCandCap = 256;
 __global__ __launch_bounds__(256) void nn_tile_candidates_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                                  const float *__restrict__ z, uint32_t n, uint32_t chunk_groups,
                                                                  const float *__restrict__ qf, const double *__restrict__ q64,
-                                                                 const uint32_t *__restrict__ bound_bits, int Q,
+                                                                 const uint32_t *__restrict__ bound_bits, int Q, int qslice,
                                                                  uint32_t *__restrict__ cand_count, double *__restrict__ cand_d2,
                                                                  uint32_t *__restrict__ cand_idx)
 {
@@ -384,8 +387,9 @@ __global__ __launch_bounds__(256) void nn_tile_candidates_kernel(const float *__
     const int lane = threadIdx.x & 63;
     const bool tail_owner = (blockIdx.x == gridDim.x - 1) && threadIdx.x < (n & 3u);   // n % 4 leftover points
 
-    for (int q0 = 0; q0 < Q; q0 += kTileQ) {
-        const int qcount = min(kTileQ, Q - q0);
+    const int q_end = min(Q, ((int)blockIdx.y + 1) * qslice);      // blockIdx.y = slice of the batch (see nn_sample_bounds_kernel)
+    for (int q0 = (int)blockIdx.y * qslice; q0 < q_end; q0 += kTileQ) {
+        const int qcount = min(kTileQ, q_end - q0);
         float qx[kTileQ], qy[kTileQ], qz[kTileQ], thr[kTileQ];
 #pragma unroll
         for (int j = 0; j < kTileQ; j++) {
