@@ -263,8 +263,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel"),
-            "kernel": "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_filter_kernel",
+            "traffic": measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel"),
+            "kernel": "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel",
             "kernel_ms": k_ms, "kernel_launches_timed": len(kern_ms), "batch_kernels_ms": b_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
             "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
         },
