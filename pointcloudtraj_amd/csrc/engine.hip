@@ -141,6 +141,7 @@ struct pct_cloud {
     double *d_part_d2 = nullptr;      // per-(query, block) partial minima of the streaming kernels: part_q x kMaxParts entries;
     uint32_t *d_part_idx = nullptr;   // larger batches go through them in slices of part_q queries
     int64_t part_q = 0;
+    uint32_t *d_ovf = nullptr;                                 // [0] = number of overflowed candidate lists, [1..] = their queries
     uint32_t *d_cand_count = nullptr, *d_cand_idx = nullptr;   // candidate lists of the brute-force filter: part_q x kCandCap
     double *d_cand_d2 = nullptr;
     // order-preserving crop (lidar): tile counts and the compacted {index, d2, x, y, z} of the last crop
@@ -479,8 +480,11 @@ int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int6
                                                                                                           d_q64, d_bound, (int)Q, cq, c->d_cand_count,
                                                                                                           c->d_cand_d2, c->d_cand_idx);
         dom_end(c, s);
-        nn_reduce_candidates_kernel<<<(int)Q, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, c->d_cand_count, c->d_cand_d2, c->d_cand_idx,
-                                                           (uint32_t)c->index_base, d_idx, d_d2);
+        HIPCHK(hipMemsetAsync(c->d_ovf, 0, sizeof(uint32_t), s));
+        nn_reduce_candidates_kernel<<<(int)Q, 256, 0, s>>>(c->d_cand_count, c->d_cand_d2, c->d_cand_idx, (uint32_t)c->index_base, c->d_ovf, d_idx, d_d2);
+        // overflowed lists (bulk exact ties): exact scan by the whole grid; both kernels return at once when there are none
+        nn_overflow_scan_kernel<<<kOvfBlocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, c->d_ovf, c->d_part_d2, c->d_part_idx);
+        nn_overflow_fold_kernel<<<(int)Q, 256, 0, s>>>(c->d_ovf, c->d_part_d2, c->d_part_idx, kOvfBlocks, (uint32_t)c->index_base, d_idx, d_d2);
         end_timing(c, s);
         HIPCHK(hipGetLastError());
         c->host_work = true;
@@ -745,7 +749,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
     dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
@@ -841,7 +845,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     const int64_t q = std::max<int64_t>(Q, 256);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
-    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
+    dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
     c->qcap = 0;
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
     PCTCHK(dev_alloc(&c->d_r, q));
@@ -866,6 +870,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     c->part_q = std::min<int64_t>(q, kPartQueries);
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)c->part_q * kMaxParts));
     PCTCHK(dev_alloc(&c->d_part_idx, (size_t)c->part_q * kMaxParts));
+    PCTCHK(dev_alloc(&c->d_ovf, (size_t)c->part_q + 1));
     PCTCHK(dev_alloc(&c->d_cand_count, (size_t)c->part_q));
     PCTCHK(dev_alloc(&c->d_cand_d2, (size_t)c->part_q * kCandCap));
     PCTCHK(dev_alloc(&c->d_cand_idx, (size_t)c->part_q * kCandCap));

@@ -362,8 +362,8 @@ __global__ __launch_bounds__(256) void nn_tile_filter_kernel(const float *__rest
 // as many points as the sample stride lie closer than the closest SAMPLED point), so here a lane that holds one evaluates it
 // exactly and appends (d2, index) to its query's candidate list in global memory; nothing else leaves the tile loop.
 // nn_reduce_candidates_kernel then folds each list by (d2, index).  A list that overflows kCandCap entries (exact ties in
-// bulk: duplicate points, lattice clouds seen from a lattice point) is resolved by that kernel with an exact scan of the
-// whole cloud for that query -- slow, rare, and still exact.
+// bulk: duplicate points, lattice clouds seen from a lattice point) is queued for nn_overflow_scan_kernel, an exact scan by the
+// whole grid -- rare, and still exact.
 constexpr uint32_t kCandCap = 256;
 
 __global__ __launch_bounds__(256) void nn_tile_candidates_kernel(const float *__restrict__ x, const float *__restrict__ y,
@@ -440,30 +440,24 @@ __global__ __launch_bounds__(256) void nn_tile_candidates_kernel(const float *__
     }
 }
 
-// one 256-thread block per query: fold its candidate list by (d2, index); re-zero the counter for the next slice.  An
-// overflowed list falls back to an exact scan of the whole cloud by this block.
-__global__ __launch_bounds__(256) void nn_reduce_candidates_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                                   const float *__restrict__ z, uint32_t n,
-                                                                   const double *__restrict__ q64, uint32_t *__restrict__ cand_count,
-                                                                   const double *__restrict__ cand_d2, const uint32_t *__restrict__ cand_idx,
-                                                                   uint32_t index_base, uint32_t *__restrict__ out_idx,
+// one 256-thread block per query: fold its candidate list by (d2, index); re-zero the counter for the next slice.  A query
+// whose list overflowed is queued (ovf[0] = count, ovf[1..] = queries) for the two kernels below.
+__global__ __launch_bounds__(256) void nn_reduce_candidates_kernel(uint32_t *__restrict__ cand_count, const double *__restrict__ cand_d2,
+                                                                   const uint32_t *__restrict__ cand_idx, uint32_t index_base,
+                                                                   uint32_t *__restrict__ ovf, uint32_t *__restrict__ out_idx,
                                                                    double *__restrict__ out_d2)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
     const int q = blockIdx.x;
     const uint32_t count = cand_count[q];
+    if (count > kCandCap) {                                   // block-uniform
+        if (threadIdx.x == 0) { ovf[1 + atomicAdd(&ovf[0], 1u)] = (uint32_t)q; cand_count[q] = 0; }
+        return;
+    }
     double d = __builtin_huge_val();
     uint32_t i = kNoIndex;
-    if (count <= kCandCap) {
-        if (threadIdx.x < count) { d = cand_d2[(size_t)q * kCandCap + threadIdx.x]; i = cand_idx[(size_t)q * kCandCap + threadIdx.x]; }
-    } else {
-        const double qx = q64[3 * q], qy = q64[3 * q + 1], qz = q64[3 * q + 2];
-        for (uint32_t p = threadIdx.x; p < n; p += 256) {
-            const double d2 = dist2((double)x[p], (double)y[p], (double)z[p], qx, qy, qz);
-            if (d2 < d) { d = d2; i = p; }                    // ids grow within a thread
-        }
-    }
+    if (threadIdx.x < count) { d = cand_d2[(size_t)q * kCandCap + threadIdx.x]; i = cand_idx[(size_t)q * kCandCap + threadIdx.x]; }
     wave_argmin(d, i);
     if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
     __syncthreads();
@@ -473,6 +467,71 @@ __global__ __launch_bounds__(256) void nn_reduce_candidates_kernel(const float *
         out_idx[q] = (i == kNoIndex) ? kNoIndex : i + index_base;
         out_d2[q] = d;
         cand_count[q] = 0;
+    }
+}
+
+// Overflowed candidate lists (bulk exact ties: a sensor that accumulates the same points frame after frame, lattice clouds
+// seen from a lattice point): the whole grid scans the cloud once more for just those queries, in exact fp64, each block its
+// own contiguous range of points; a second kernel folds the per-block winners.  Both are launched after every slice and
+// return at once when nothing overflowed (ovf[0] == 0), so the host never has to read the count back.
+constexpr int kOvfBlocks = 1024;
+
+__global__ __launch_bounds__(256) void nn_overflow_scan_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                               const float *__restrict__ z, uint32_t n, const double *__restrict__ q64,
+                                                               const uint32_t *__restrict__ ovf, double *__restrict__ part_d2,
+                                                               uint32_t *__restrict__ part_idx)
+{
+    const uint32_t count = ovf[0];
+    if (count == 0) return;
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t begin = min(n, blockIdx.x * per), end = min(n, begin + per);
+    for (uint32_t m = 0; m < count; m++) {
+        const uint32_t q = ovf[1 + m];
+        const double qx = q64[3 * q], qy = q64[3 * q + 1], qz = q64[3 * q + 2];
+        double d = __builtin_huge_val();
+        uint32_t i = kNoIndex;
+        for (uint32_t p = begin + threadIdx.x; p < end; p += 256) {
+            const double d2 = dist2((double)x[p], (double)y[p], (double)z[p], qx, qy, qz);
+            if (d2 < d) { d = d2; i = p; }                    // ids grow within a thread
+        }
+        wave_argmin(d, i);
+        __syncthreads();                                      // previous round's s_d / s_i have been read
+        if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; w++)
+                if (better(s_d[w], s_i[w], d, i)) { d = s_d[w]; i = s_i[w]; }
+            part_d2[(size_t)m * gridDim.x + blockIdx.x] = d;
+            part_idx[(size_t)m * gridDim.x + blockIdx.x] = i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nn_overflow_fold_kernel(const uint32_t *__restrict__ ovf, const double *__restrict__ part_d2,
+                                                               const uint32_t *__restrict__ part_idx, int nparts, uint32_t index_base,
+                                                               uint32_t *__restrict__ out_idx, double *__restrict__ out_d2)
+{
+    if (blockIdx.x >= ovf[0]) return;
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const uint32_t q = ovf[1 + blockIdx.x];
+    double d = __builtin_huge_val();
+    uint32_t i = kNoIndex;
+    for (int p = threadIdx.x; p < nparts; p += 256) {
+        const double pd = part_d2[(size_t)blockIdx.x * nparts + p];
+        const uint32_t pi = part_idx[(size_t)blockIdx.x * nparts + p];
+        if (better(pd, pi, d, i)) { d = pd; i = pi; }
+    }
+    wave_argmin(d, i);
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = d; s_i[threadIdx.x >> 6] = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (better(s_d[w], s_i[w], d, i)) { d = s_d[w]; i = s_i[w]; }
+        out_idx[q] = (i == kNoIndex) ? kNoIndex : i + index_base;
+        out_d2[q] = d;
     }
 }
 

@@ -559,3 +559,32 @@ def test_streaming_batches_larger_than_the_partial_buffers(E, oracle):
     bi, bd = oracle.brute_nearest(pts, q[pick])
     assert np.array_equal(d1[pick], bd) and np.array_equal(i1[pick].astype(np.int64), bi.astype(np.int64))
     c.close()
+
+
+@pytest.mark.gpu
+def test_brute_force_with_bulk_duplicates(E, oracle):
+    """A sensor that keeps every frame (camera_sensor.cpp:160-166) repeats the same points hundreds of times: every query's
+    nearest point then has hundreds of exact ties, its candidate list overflows, and the grid-wide exact fallback must return
+    the LOWEST index among them -- without falling off a performance cliff (one block per query used to scan the cloud)."""
+    import time
+    base = synth.uniform_points(81, 1500, 0, 30)
+    order = synth.shuffled_order(82, 1500 * 400)
+    pts = np.repeat(base, 400, axis=0)[order]                    # 600 000 points, 400 copies of each, interleaved
+    q = np.concatenate([synth.uniform_points(83, 500, -2, 32), base[:12]])
+    c = make_cloud(E, pts)
+    c.nn(q[:8], E.ALGO_STREAM)                                   # warm-up
+    t0 = time.perf_counter()
+    i1, d1 = c.nn(q, E.ALGO_STREAM)
+    dt = time.perf_counter() - t0
+    bi, bd = oracle.brute_nearest(pts, q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    # lowest index among the 400 copies, cross-checked without the oracle
+    first = np.full(1500, len(pts), np.int64)
+    np.minimum.at(first, order // 400, np.arange(len(pts)))
+    src = order[i1.astype(np.int64)] // 400
+    assert np.array_equal(i1.astype(np.int64), first[src])
+    assert dt < 0.5, f"512 queries with overflowing candidate lists took {dt * 1e3:.1f} ms"
+    c.build_grid()
+    i2, d2 = c.nn(q, E.ALGO_GRID)
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    c.close()
