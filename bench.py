@@ -78,6 +78,9 @@ def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
     orders = np.int32([6, 6, 6])
     seg_time = np.float64([1.0, 1.0, 1.0])
     t_ing, t_cor, t_bez = [], [], []
+    import gc
+    gc.collect()
+    gc.disable()                                   # a generation-2 collection of the interpreter (40 ms) used to land in one tick
     for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (workspaces, first launches)
         x0 = 0.1 * k
         new_frame = frame_pts(k)                  # the sensor's output: produced outside the timed region
@@ -100,6 +103,7 @@ def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
         t3 = time.perf_counter()
         if k >= nfill:
             t_ing.append(1e3 * (t1 - t0)); t_cor.append(1e3 * (t2 - t1)); t_bez.append(1e3 * (t3 - t2))
+    gc.enable()
     tot = np.asarray(t_ing) + np.asarray(t_cor) + np.asarray(t_bez)
     cloud.close()
     pct = lambda a, q: float(np.percentile(a, q))
