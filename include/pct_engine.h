@@ -171,6 +171,11 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
  * graph capture.  An empty shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ---------------------- */
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream);
+/* Exchange step of a sharded cloud (one process per GPU): between all_reduce(min) on the squared distances and all_reduce(min) on
+ * the indices, a rank offers its global index only where its own d2 equals the reduced minimum (and is finite), INT32_MAX
+ * elsewhere -- so the second reduction returns the lowest global index among the ranks that tie.  Device pointers, async on
+ * `stream`; global indices must be < 2^31 - 1. */
+int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const uint32_t *d_idx_local, int32_t *d_cand, int64_t Q, void *stream);
 /* make sure workspaces for batches up to Q exist (call before capturing a graph) */
 int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q);
 

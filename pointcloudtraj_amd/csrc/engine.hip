@@ -1507,6 +1507,17 @@ int pct_last_kernel_ms(pct_cloud *c, float *ms)
     return PCT_OK;
 }
 
+// multi-GPU exchange helper (pointcloudtraj_amd/dist.py): cand[i] = idx_local[i] if this rank holds the global minimum, else INT32_MAX
+int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const uint32_t *d_idx_local, int32_t *d_cand, int64_t Q, void *stream)
+{
+    if (Q < 0 || (Q > 0 && (!d_d2_local || !d_d2_best || !d_idx_local || !d_cand))) return fail(PCT_ERR_INVALID, "bad merge_mask arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(require_init());
+    merge_mask_kernel<<<ceil_div(Q, 256), 256, 0, (hipStream_t)stream>>>(d_d2_local, d_d2_best, d_idx_local, d_cand, (uint32_t)Q);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
 int pct_set_timing(pct_cloud *c, int level)
 {
     if (!c || level < 0 || level > 2) return fail(PCT_ERR_INVALID, "timing level must be 0, 1 or 2");

@@ -535,6 +535,18 @@ __global__ __launch_bounds__(256) void nn_overflow_fold_kernel(const uint32_t *_
     }
 }
 
+// Exchange step of the sharded cloud, between its two all_reduce(min) calls: a rank stays in the race for a query only if its own
+// squared distance IS the global minimum; everybody else offers INT32_MAX.  One pass instead of five elementwise kernels.
+__global__ __launch_bounds__(256) void merge_mask_kernel(const double *__restrict__ d2_local, const double *__restrict__ d2_best,
+                                                         const uint32_t *__restrict__ idx_local, int32_t *__restrict__ cand, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = d2_local[i];
+    const uint32_t ix = idx_local[i];
+    cand[i] = (d == d2_best[i] && d < __builtin_huge_val() && ix <= 0x7FFFFFFEu) ? (int32_t)ix : 0x7FFFFFFF;
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

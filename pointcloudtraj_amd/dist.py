@@ -117,6 +117,9 @@ class ShardedCloud:
                         torch.empty(Q, dtype=torch.float64, device=self.device)) for _ in range(max(depth, 1))]
         self._idx32, self._d2 = self._slots[0]
         self._cnt = torch.empty(Q, dtype=torch.int32, device=self.device)
+        # pipelined exchange (nn_submit over RCCL): reduced distances and candidate / merged indices per slot
+        self._merged = [(torch.empty(Q, dtype=torch.float64, device=self.device), torch.empty(Q, dtype=torch.int32, device=self.device))
+                        for _ in self._slots] if self.world > 1 else []
         self._slot_free = [None] * len(self._slots)   # event: the exchange that last read this slot has finished
         self._next_slot = 0
         self._comm = torch.cuda.Stream(device=self.device) if self.world > 1 else None
@@ -168,6 +171,16 @@ class ShardedCloud:
             idx.record_stream(self._comm)
             if idx.is_cuda and dist.get_backend(self.group) == "gloo":
                 best, cand = merge_nearest(d2, idx, self.group)         # rehearsal: staged through the host
+            elif idx.dtype == torch.int32:
+                # RCCL, indices < 2^31: copy + all_reduce(min) on d2, ONE fused mask kernel (pct_merge_mask_dev), all_reduce(min)
+                # on the masked indices -- into this slot's preallocated buffers (valid until the slot is reused, i.e. until the
+                # second submit after this one).  idx comes back as int32, INT32_MAX = no point anywhere.
+                Q = q.shape[0]
+                best, cand = self._merged[slot][0][:Q], self._merged[slot][1][:Q]
+                best.copy_(d2)
+                dist.all_reduce(best, op=dist.ReduceOp.MIN, group=self.group)
+                self.E.merge_mask_device(d2.data_ptr(), best.data_ptr(), idx32.data_ptr(), cand.data_ptr(), Q, self._comm.cuda_stream)
+                dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=self.group)
             else:
                 best, cand = _merge_nearest(d2, idx, self.group)
             done = torch.cuda.Event()

@@ -97,6 +97,7 @@ def lib():
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         L.pct_set_timing.argtypes = [vp, C.c_int]
+        L.pct_merge_mask_dev.argtypes = [vp, vp, vp, vp, i64, vp]
         L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_set_work_counters.argtypes = [vp, i32]
         _lib = L
@@ -122,6 +123,11 @@ def sync():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def merge_mask_device(d2_local_ptr: int, d2_best_ptr: int, idx_local_ptr: int, cand_ptr: int, Q: int, stream: int = 0):
+    """cand[i] = idx_local[i] where d2_local[i] is the reduced minimum (and finite), INT32_MAX elsewhere (pct_merge_mask_dev)"""
+    _chk(lib().pct_merge_mask_dev(d2_local_ptr, d2_best_ptr, idx_local_ptr, cand_ptr, int(Q), stream))
 
 
 def inflate_params(start, sample_range, search_margin, max_radius) -> InflateParams:

@@ -66,3 +66,28 @@ def test_two_rank_sharded_cloud_on_one_card(tmp_path):
     O.build()
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok").read() == "1"
+
+
+def test_fused_merge_mask_equals_the_elementwise_recipe():
+    """pct_merge_mask_dev (the one kernel between the two all_reduce(min) calls over RCCL) against dist._merge_nearest's
+    elementwise formula, including +inf distances (empty shard), NO_INDEX and exact ties."""
+    import torch
+    from pointcloudtraj_amd import engine as E
+    E.init(0)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    Q = 100_003
+    mine = torch.rand(Q, generator=g, dtype=torch.float64)
+    other = torch.rand(Q, generator=g, dtype=torch.float64)
+    other[::7] = mine[::7]                                  # exact ties
+    mine[::11] = float("inf")                               # this shard saw nothing
+    other[::33] = float("inf")
+    idx = torch.randint(0, 2 ** 31 - 2, (Q,), generator=g, dtype=torch.int64)
+    idx[::11] = 0xFFFFFFFF
+    best = torch.minimum(mine, other)
+    want = torch.where((mine == best) & torch.isfinite(mine), idx, torch.full_like(idx, 2 ** 31 - 1)).to(torch.int32)
+    d_m, d_b = mine.cuda(), best.cuda()
+    d_i32 = torch.from_numpy((idx.numpy() & 0xFFFFFFFF).astype("uint32").view("int32")).cuda()    # u32 bit patterns
+    out = torch.empty(Q, dtype=torch.int32, device="cuda")
+    E.merge_mask_device(d_m.data_ptr(), d_b.data_ptr(), d_i32.data_ptr(), out.data_ptr(), Q, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), want)
