@@ -111,7 +111,8 @@ class ShardedCloud:
 
     def reserve(self, Q: int, depth: int = 2):
         """Result buffers for batches of up to Q queries; `depth` sets of them so that the exchange step of one
-        batch can overlap the kernels of the next (nn_submit)."""
+        batch can overlap the kernels of the next (nn_submit).  A result handed out by nn_submit lives in its set and is
+        overwritten by the depth-th submit after it."""
         self.cloud.reserve_queries(Q)
         self._slots = [(torch.empty(Q, dtype=torch.int32, device=self.device),
                         torch.empty(Q, dtype=torch.float64, device=self.device)) for _ in range(max(depth, 1))]
@@ -169,7 +170,8 @@ class ShardedCloud:
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ready)
             idx.record_stream(self._comm)
-            if idx.is_cuda and dist.get_backend(self.group) == "gloo":
+            staged = idx.is_cuda and dist.get_backend(self.group) == "gloo" and os.environ.get("PCT_DIST_DEVICE_COLLECTIVES") != "1"
+            if staged:
                 best, cand = merge_nearest(d2, idx, self.group)         # rehearsal: staged through the host
             elif idx.dtype == torch.int32:
                 # RCCL, indices < 2^31: copy + all_reduce(min) on d2, ONE fused mask kernel (pct_merge_mask_dev), all_reduce(min)

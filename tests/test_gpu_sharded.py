@@ -14,10 +14,10 @@ from test_dist_gloo import ROOT, _free_port
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, device_collectives):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", PCT_DIST_BACKEND="gloo")
+                      LOCAL_RANK="0", PCT_DIST_BACKEND="gloo", PCT_DIST_DEVICE_COLLECTIVES="1" if device_collectives else "0")
     import torch
     import torch.distributed as dist
     from pointcloudtraj_amd import dist as D, engine as E, synth
@@ -28,7 +28,7 @@ def _worker(rank, world, port, out_dir):
     sc.set_input_local(pts[sc.begin:sc.end])
     sc.build_grid()
     batches = [np.concatenate([synth.uniform_points(20 + k, 20_000, -3, 33), base[k::97][:500]]) for k in range(4)]
-    sc.reserve(max(len(b) for b in batches))
+    sc.reserve(max(len(b) for b in batches), depth=4)     # the three pipelined results below are read after the last submit
     outs = []
     for k, qh in enumerate(batches):
         q = torch.from_numpy(qh).to(sc.device)
@@ -61,10 +61,13 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_cloud_on_one_card(tmp_path):
+@pytest.mark.parametrize("device_collectives", [False, True])
+def test_two_rank_sharded_cloud_on_one_card(tmp_path, device_collectives):
+    """device_collectives=True runs nn_submit's RCCL code path (collectives on device tensors, the fused mask kernel, per-slot
+    result buffers) with gloo doing the transport; False is the host-staged rehearsal path."""
     from oracle import oracle as O
     O.build()
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), device_collectives), nprocs=2, join=True)
     assert open(tmp_path / "ok").read() == "1"
 
 
