@@ -1,0 +1,76 @@
+"""Randomised differential test of the three NN paths and the two count paths (GPU): clouds of assorted size, shape and
+duplication; queries inside, on and far outside the cloud; every configuration must give bit-identical (index, d2) from the
+cell-pruned kernel, the brute-force filter and the all-fp64 kernel, equal counts from the indexed and brute-force radius
+count, and agree with the exhaustive CPU oracle on a sample.  PCT_SOAK_CONFIGS scales it up for a manual soak."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pointcloudtraj_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def make_case(rng, k):
+    n = int(rng.choice([1, 3, 17, 255, 1000, 4097, 30_000, 200_000, 1_000_000], p=[.04, .04, .06, .08, .14, .14, .2, .2, .1]))
+    kind = rng.choice(["uniform", "lattice", "flat", "clusters", "dups", "line"])
+    ext = float(rng.choice([0.5, 10.0, 100.0, 3000.0]))
+    off = rng.uniform(-ext, ext, 3) * float(rng.choice([0.0, 1.0, 50.0]))
+    u = rng.random((n, 3))
+    if kind == "uniform":
+        p = u * ext
+    elif kind == "lattice":
+        p = np.round(u * 12) / 12 * ext
+    elif kind == "flat":
+        p = u * [ext, ext, ext * 1e-3]
+    elif kind == "clusters":
+        c = rng.random((8, 3)) * ext
+        p = c[rng.integers(0, 8, n)] + rng.normal(0, ext * 0.01, (n, 3))
+    elif kind == "dups":
+        m = max(1, n // 50)
+        p = (rng.random((m, 3)) * ext)[rng.integers(0, m, n)]
+    else:
+        p = np.outer(u[:, 0], [1.0, 0.5, 0.25]) * ext
+    pts = (p + off).astype(np.float32)
+    nq = int(rng.choice([1, 5, 64, 700, 20_000], p=[.1, .1, .3, .3, .2]))
+    q = np.concatenate([
+        (rng.random((nq, 3)) * ext * 1.2 - 0.1 * ext + off),                 # around the cloud
+        pts[rng.integers(0, n, max(1, nq // 8))].astype(np.float64),          # exactly on cloud points
+        (rng.random((max(1, nq // 16), 3)) - 0.5) * ext * 40 + off,          # far outside
+    ]).astype(np.float32)
+    return f"{k}:{kind}:n={n}:q={len(q)}:ext={ext}", pts, q, ext
+
+
+def test_randomised_paths_agree():
+    import torch  # noqa: F401
+    from pointcloudtraj_amd import engine as E
+    from oracle import oracle as O
+    E.init(0)
+    O.build()
+    rng = np.random.default_rng(20240611)
+    ncfg = int(os.environ.get("PCT_SOAK_CONFIGS", "36"))
+    for k in range(ncfg):
+        name, pts, q, ext = make_case(rng, k)
+        c = E.Cloud(len(pts))
+        c.set_input(pts)
+        i1, d1 = c.nn(q, E.ALGO_STREAM)
+        i2, d2 = c.nn(q, E.ALGO_STREAM_EXACT) if len(pts) * len(q) <= 4e9 else (i1, d1)
+        r = np.float32(ext * float(rng.choice([0.0, 0.01, 0.08, 0.3])))
+        rad = np.full(len(q), r, np.float32)
+        cb = c.radius_count(q[:2000], rad[:2000], E.ALGO_STREAM)
+        c.build_grid()
+        i3, d3 = c.nn(q, E.ALGO_GRID)
+        cg = c.radius_count(q[:2000], rad[:2000], E.ALGO_GRID)
+        assert np.array_equal(d1, d2) and np.array_equal(i1, i2), name + " filter vs all-fp64"
+        assert np.array_equal(d1, d3) and np.array_equal(i1, i3), name + " brute force vs cell-pruned"
+        assert np.array_equal(cb, cg), name + " radius count"
+        pick = rng.integers(0, len(q), min(len(q), max(4, int(2e7 // len(pts)))))
+        bi, bd = O.brute_nearest(pts, q[pick])
+        assert np.array_equal(d1[pick], bd) and np.array_equal(i1[pick].astype(np.int64), bi.astype(np.int64)), name + " vs oracle"
+        wc = O.brute_count(pts, q[pick[:64]], float(r))
+        assert np.array_equal(c.radius_count(q[pick[:64]], rad[:len(pick[:64])], E.ALGO_GRID), wc), name + " count vs oracle"
+        c.close()
