@@ -73,4 +73,16 @@ def test_randomised_paths_agree():
         assert np.array_equal(d1[pick], bd) and np.array_equal(i1[pick].astype(np.int64), bi.astype(np.int64)), name + " vs oracle"
         wc = O.brute_count(pts, q[pick[:64]], float(r))
         assert np.array_equal(c.radius_count(q[pick[:64]], rad[:len(pick[:64])], E.ALGO_GRID), wc), name + " count vs oracle"
+        # lidar crop (order-preserving compaction) and sphere inflation on the same cloud
+        centre = q[int(rng.integers(0, len(q)))].astype(np.float64)
+        d = pts.astype(np.float64) - centre
+        dd = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        want = np.nonzero(dd <= float(r) * float(r))[0]
+        ci, cd, cxyz = c.radius_crop(centre, float(r))
+        assert np.array_equal(ci, want) and np.array_equal(cd, dd[want]) and np.array_equal(cxyz, pts[want]), name + " crop"
+        prm = E.inflate_params(centre, 1e30, 0.25 * ext * 0.01, ext * 0.05)
+        sel = q[pick[:200]].astype(np.float64)
+        rad_i, idx_i, d2_i = c.inflate(prm, sel)
+        assert np.array_equal(d2_i, d1[pick[:200]]) and np.array_equal(idx_i, i1[pick[:200]]), name + " inflation NN"
+        assert np.array_equal(rad_i, np.minimum(np.sqrt(d2_i) - 0.25 * ext * 0.01, ext * 0.05)), name + " inflation radius"
         c.close()
