@@ -74,3 +74,18 @@ def test_corridor_exports_every_declared_symbol(built):
     L = C2.CDLL(built.CORRIDOR_SO)        # pulls libkdtree.so and libpct_engine.so through DT_NEEDED, local scope
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
+
+
+def test_public_headers_are_plain_c99_and_cxx17():
+    """The drop-in boundary is a C ABI: every include/*.h must compile as C99 on its own (no C++, no torch/HIP types), and the
+    two C++ mirrors as C++17 without any GPU toolchain header."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    for h in ("pct_engine.h", "pct_voxel.h", "pct_traj.h", "pct_corridor.h", "kdtree/kdtree.h", "kdtree/kdtree_ext.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + inc, "-x", "c", "-fsyntax-only", "-"],
+                           input=f'#include "{h}"\n', text=True, capture_output=True)
+        assert r.returncode == 0, h + ":\n" + r.stderr
+    for h in ("pct_obstacle_map.hpp", "pct_corridor_finder.hpp"):
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + inc, "-x", "c++", "-fsyntax-only", "-"],
+                           input=f'#include "{h}"\n', text=True, capture_output=True)
+        assert r.returncode == 0, h + ":\n" + r.stderr
