@@ -392,15 +392,26 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         int key_shift = 0;
         while ((((uint64_t)B.nbins - 1) >> key_shift) >= (1ull << 20)) key_shift++;
         uint32_t *total1 = c->d_sort1, *start1 = c->d_sort1 + kSortBuckets, *fill1 = c->d_sort1 + 2 * kSortBuckets + 4;
+        // PCT_SORT_LEVELS: 1 (default) = one counting pass into <= 1024 spatial buckets, queries left in arrival order inside a
+        // bucket; 2 = a second pass orders every bucket by the remaining key bits.  With the block-first search the finer order
+        // no longer pays for its pass (same-box: 0.198-0.204 ms per step with it, 0.168 without).
+        static const int levels = [] { const char *e = std::getenv("PCT_SORT_LEVELS"); return e ? std::max(1, std::min(2, std::atoi(e))) : 1; }();
+        int lshift = 10;                         // level-1 bucket = key >> 10 (keys < 2^20): finer buckets (key >> 8, >> 9) measured the same
+        if (const char *e = std::getenv("PCT_SORT_LSHIFT")) lshift = std::max(10, std::atoi(e));   // coarser buckets (tuning, single-level mode)
         static const int per_block_env = [] { const char *e = std::getenv("PCT_SORT_PER_BLOCK"); return e ? std::max(1024, std::atoi(e)) : 0; }();
         // ~128 blocks: small batches want parallelism (64 K queries: 21 us at 1024 per block, 36 us at 8192), large ones
         // want long per-block bucket slices (1 M: 67 us at 8192, 87 us at 1024)
         const uint32_t per_block = per_block_env ? (uint32_t)per_block_env
                                                  : (uint32_t)std::min<int64_t>(kSortPerBlock, std::max<int64_t>(1024, (Q / 128 + 1023) / 1024 * 1024));
         const int nb = ceil_div(Q, (int64_t)per_block);
-        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, d_q, (uint32_t)Q, per_block, c->d_qbin, total1, fill1);
-        qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, total1, fill1, start1, c->d_sortkey, c->d_sorttmp);
-        qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, c->d_perm, c->d_qsorted);
+        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, per_block, c->d_qbin, total1, fill1);
+        if (levels == 1) {
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, c->d_perm);
+            HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));       // the fine pass would have re-zeroed it
+        } else {
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr);
+            qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, c->d_perm, c->d_qsorted);
+        }
         HIPCHK(hipGetLastError());
         *perm_out = c->d_perm;
         return PCT_OK;

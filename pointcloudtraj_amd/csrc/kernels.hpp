@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
     qsorted[pos] = make_float4(q[3 * t], q[3 * t + 1], q[3 * t + 2], __uint_as_float(t));
 }
 
-// Two-level counting sort of the batch on LDS histograms (replaces the global-atomic version
+// Counting sort of the batch on LDS histograms, one or two levels (replaces the global-atomic version
 // above for large batches: 2 M scattered device-scope atomics ran at ~20 G/s = 100 us per 1 M
 // queries, profiles/r01_d).  key = bin >> key_shift (< 2^20); level 1 = key >> 10 (<= 1024
 // buckets), level 2 = key & 1023 inside a bucket.  Global atomics are one per (block, non-empty
@@ -1032,7 +1032,7 @@ constexpr int kSortPerBlock = 8192;      // most queries per block in the level-
 // (~40 us for five dependent operations, measured), so the bucket scan lives inside scatter1 and the two counter
 // arrays are re-zeroed by the kernels themselves instead of by memsets: total1 is zero on entry (zeroed at allocation,
 // then by the fine kernel of the previous batch), fill1 is zeroed here, before any scatter1 block can touch it.
-__global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, const float *__restrict__ q,
+__global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, int lshift, const float *__restrict__ q,
                                                           uint32_t Q, uint32_t per_block, uint32_t *__restrict__ keys,
                                                           uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1)
 {
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
         if (t < Q) {
             const uint32_t key = query_bin(G, B, q[3 * t], q[3 * t + 1], q[3 * t + 2]) >> key_shift;
             keys[t] = key;
-            atomicAdd(&h[key >> 10], 1u);
+            atomicAdd(&h[key >> lshift], 1u);
         }
     }
     __syncthreads();
@@ -1059,9 +1059,10 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
 // never gathers from the (randomly ordered) input again.  Every block scans the 1024 bucket totals itself
 // (thread i = bucket i) instead of waiting for a one-block scan kernel; block 0 publishes the starts for the fine pass.
 __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__restrict__ keys, const float *__restrict__ q,
-                                                              uint32_t Q, uint32_t per_block, const uint32_t *__restrict__ total1,
+                                                              uint32_t Q, uint32_t per_block, int lshift, const uint32_t *__restrict__ total1,
                                                               uint32_t *__restrict__ fill1, uint32_t *__restrict__ start1,
-                                                              uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec)
+                                                              uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec,
+                                                              uint32_t *__restrict__ perm)
 {
     static_assert(kSortBuckets == 1024, "one thread per bucket");
     __shared__ uint32_t h[kSortBuckets];
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
     const uint32_t base = blockIdx.x * per_block;
     for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
         const uint32_t t = base + i;
-        if (t < Q) atomicAdd(&h[keys[t] >> 10], 1u);
+        if (t < Q) atomicAdd(&h[keys[t] >> lshift], 1u);
     }
     __syncthreads();
     {
@@ -1100,8 +1101,9 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
         const uint32_t t = base + i;
         if (t < Q) {
             const uint32_t key = keys[t];
-            const uint32_t pos = basepos[key >> 10] + atomicAdd(&h[key >> 10], 1u);
-            tmp_key[pos] = key;
+            const uint32_t pos = basepos[key >> lshift] + atomicAdd(&h[key >> lshift], 1u);
+            if (perm) perm[pos] = t;                  // single-level mode: this IS the final order
+            else tmp_key[pos] = key;
             tmp_rec[pos] = make_float4(q[3 * t], q[3 * t + 1], q[3 * t + 2], __uint_as_float(t));
         }
     }
@@ -1114,7 +1116,7 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
 constexpr int kFineThreads = 1024;
 __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
                                                                   const uint32_t *__restrict__ start1, uint32_t *__restrict__ total1,
-                                                                  uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
+                                                                  uint32_t lmask, uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
 {
     static_assert(kSortBuckets == kFineThreads, "one histogram entry per thread");
     __shared__ uint32_t h[kSortBuckets];
@@ -1124,7 +1126,7 @@ __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t
     if (s == e) return;
     h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) atomicAdd(&h[tmp_key[i] & 1023u], 1u);
+    for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) atomicAdd(&h[tmp_key[i] & lmask], 1u);
     __syncthreads();
     // exclusive scan of h[1024] in place: one entry per thread
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1143,7 +1145,7 @@ __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t
     __syncthreads();
     for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) {
         const float4 rec = tmp_rec[i];
-        const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & 1023u], 1u);
+        const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & lmask], 1u);
         perm[pos] = __float_as_uint(rec.w);
         qsorted[pos] = rec;
     }
