@@ -36,40 +36,40 @@ struct kdtree;   /* opaque */
 struct kdres;    /* opaque */
 
 /* lifecycle -- kdtree.c:112-164 */
-struct kdtree *kd_create(int k);
-void kd_free(struct kdtree *tree);
-void kd_clear(struct kdtree *tree);
-void kd_data_destructor(struct kdtree *tree, void (*destr)(void *));
+struct kdtree *kd_create(int dimensions);
+void kd_free(struct kdtree *kd);
+void kd_clear(struct kdtree *kd);
+void kd_data_destructor(struct kdtree *kd, void (*on_clear)(void *payload));
 
 /* insertion, 0 on success / -1 on allocation failure -- kdtree.c:167-260 */
-int kd_insert(struct kdtree *tree, const double *pos, void *data);
-int kd_insertf(struct kdtree *tree, const float *pos, void *data);
-int kd_insert3(struct kdtree *tree, double x, double y, double z, void *data);
-int kd_insert3f(struct kdtree *tree, float x, float y, float z, void *data);
+int kd_insert(struct kdtree *kd, const double *xyz, void *payload);
+int kd_insertf(struct kdtree *kd, const float *xyz, void *payload);
+int kd_insert3(struct kdtree *kd, double px, double py, double pz, void *payload);
+int kd_insert3f(struct kdtree *kd, float px, float py, float pz, void *payload);
 
 /* exact nearest neighbour: result set of size 1, or NULL -- kdtree.c:345-509 */
-struct kdres *kd_nearest(struct kdtree *tree, const double *pos);
-struct kdres *kd_nearestf(struct kdtree *tree, const float *pos);
-struct kdres *kd_nearest3(struct kdtree *tree, double x, double y, double z);
-struct kdres *kd_nearest3f(struct kdtree *tree, float x, float y, float z);
+struct kdres *kd_nearest(struct kdtree *kd, const double *xyz);
+struct kdres *kd_nearestf(struct kdtree *kd, const float *xyz);
+struct kdres *kd_nearest3(struct kdtree *kd, double px, double py, double pz);
+struct kdres *kd_nearest3f(struct kdtree *kd, float px, float py, float pz);
 
 /* all nodes within `range` (inclusive) -- kdtree.c:262-293, 537-611 */
-struct kdres *kd_nearest_range(struct kdtree *tree, const double *pos, double range);
-struct kdres *kd_nearest_rangef(struct kdtree *tree, const float *pos, float range);
-struct kdres *kd_nearest_range3(struct kdtree *tree, double x, double y, double z, double range);
-struct kdres *kd_nearest_range3f(struct kdtree *tree, float x, float y, float z, float range);
+struct kdres *kd_nearest_range(struct kdtree *kd, const double *xyz, double radius);
+struct kdres *kd_nearest_rangef(struct kdtree *kd, const float *xyz, float radius);
+struct kdres *kd_nearest_range3(struct kdtree *kd, double px, double py, double pz, double radius);
+struct kdres *kd_nearest_range3f(struct kdtree *kd, float px, float py, float pz, float radius);
 
 /* result-set cursor -- kdtree.c:613-689 */
-void kd_res_free(struct kdres *set);
-int kd_res_size(struct kdres *set);
-void kd_res_rewind(struct kdres *set);
-int kd_res_end(struct kdres *set);
-int kd_res_next(struct kdres *set);
-void *kd_res_item(struct kdres *set, double *pos);
-void *kd_res_itemf(struct kdres *set, float *pos);
-void *kd_res_item3(struct kdres *set, double *x, double *y, double *z);
-void *kd_res_item3f(struct kdres *set, float *x, float *y, float *z);
-void *kd_res_item_data(struct kdres *set);
+void kd_res_free(struct kdres *rs);
+int kd_res_size(struct kdres *rs);
+void kd_res_rewind(struct kdres *rs);
+int kd_res_end(struct kdres *rs);
+int kd_res_next(struct kdres *rs);
+void *kd_res_item(struct kdres *rs, double *xyz_out);
+void *kd_res_itemf(struct kdres *rs, float *xyz_out);
+void *kd_res_item3(struct kdres *rs, double *px, double *py, double *pz);
+void *kd_res_item3f(struct kdres *rs, float *px, float *py, float *pz);
+void *kd_res_item_data(struct kdres *rs);
 
 #ifdef __cplusplus
 }
