@@ -398,7 +398,7 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         static const int levels = [] { const char *e = std::getenv("PCT_SORT_LEVELS"); return e ? std::max(1, std::min(2, std::atoi(e))) : 1; }();
         int lshift = 10;                         // level-1 bucket = key >> 10 (keys < 2^20): finer buckets (key >> 8, >> 9) measured the same
         if (const char *e = std::getenv("PCT_SORT_LSHIFT")) lshift = std::max(10, std::atoi(e));   // coarser buckets (tuning, single-level mode)
-        static const int per_block_env = [] { const char *e = std::getenv("PCT_SORT_PER_BLOCK"); return e ? std::max(1024, std::atoi(e)) : 0; }();
+        static const int per_block_env = [] { const char *e = std::getenv("PCT_SORT_PER_BLOCK"); return e ? std::min(kSortPerBlock, std::max(1024, std::atoi(e) / 1024 * 1024)) : 0; }();
         // ~128 blocks: small batches want parallelism (64 K queries: 21 us at 1024 per block, 36 us at 8192), large ones
         // want long per-block bucket slices (1 M: 67 us at 8192, 87 us at 1024)
         const uint32_t per_block = per_block_env ? (uint32_t)per_block_env

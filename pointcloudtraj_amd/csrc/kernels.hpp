@@ -1025,13 +1025,14 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
 // buckets), level 2 = key & 1023 inside a bucket.  Global atomics are one per (block, non-empty
 // bucket); everything else is LDS atomics and coalesced traffic.
 constexpr int kSortBuckets = 1024;
-constexpr int kSortPerBlock = 8192;      // most queries per block in the level-1 kernels (engine.hip picks 1024..8192 by batch size)
+constexpr int kSortItems = 8;            // queries per thread in the level-1 kernels
+constexpr int kSortPerBlock = 1024 * kSortItems;      // most queries per block in the level-1 kernels (engine.hip picks 1024..8192 by batch size)
 
 //
 // Three dependent launches per batch (hist -> scatter1 -> fine); at <= 256 K queries the sort is launch-latency-bound
 // (~40 us for five dependent operations, measured), so the bucket scan lives inside scatter1 and the two counter
-// arrays are re-zeroed by the kernels themselves instead of by memsets: total1 is zero on entry (zeroed at allocation,
-// then by the fine kernel of the previous batch), fill1 is zeroed here, before any scatter1 block can touch it.
+// arrays are re-zeroed without extra launches where possible: total1 is zero on entry (zeroed at allocation, then by the fine
+// kernel or, in single-level mode, a memset behind scatter1), fill1 is zeroed here, before any scatter1 block can touch it.
 __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, int lshift, const float *__restrict__ q,
                                                           uint32_t Q, uint32_t per_block, uint32_t *__restrict__ keys,
                                                           uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1)
@@ -1042,10 +1043,20 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
     for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * per_block;
-    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
-        const uint32_t t = base + i;
-        if (t < Q) {
-            const uint32_t key = query_bin(G, B, q[3 * t], q[3 * t + 1], q[3 * t + 2]) >> key_shift;
+    const int items = (int)(per_block >> 10);             // per_block is a multiple of 1024, at most kSortPerBlock
+    // all of a thread's queries are requested before the first is used: the loop used to pay one memory round trip per item
+    float qv[kSortItems][3];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+        const bool ok = k < items && t < Q;
+        qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+        if (k < items && t < Q) {
+            const uint32_t key = query_bin(G, B, qv[k][0], qv[k][1], qv[k][2]) >> key_shift;
             keys[t] = key;
             atomicAdd(&h[key >> lshift], 1u);
         }
@@ -1086,10 +1097,20 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
         if (threadIdx.x == kSortBuckets - 1) start1[kSortBuckets] = start + tot;
     }
     const uint32_t base = blockIdx.x * per_block;
-    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
-        const uint32_t t = base + i;
-        if (t < Q) atomicAdd(&h[keys[t] >> lshift], 1u);
+    const int items = (int)(per_block >> 10);
+    // keys and queries of all of a thread's items are requested up front (one round trip for each array instead of one per item)
+    uint32_t key[kSortItems];
+    float qv[kSortItems][3];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+        const bool ok = k < items && t < Q;
+        key[k] = ok ? keys[t] : 0xFFFFFFFFu;
+        qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
     }
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++)
+        if (key[k] != 0xFFFFFFFFu) atomicAdd(&h[key[k] >> lshift], 1u);
     __syncthreads();
     {
         const uint32_t mine = h[threadIdx.x];
@@ -1097,14 +1118,14 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
         h[threadIdx.x] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < per_block; i += 1024) {
-        const uint32_t t = base + i;
-        if (t < Q) {
-            const uint32_t key = keys[t];
-            const uint32_t pos = basepos[key >> lshift] + atomicAdd(&h[key >> lshift], 1u);
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        if (key[k] != 0xFFFFFFFFu) {
+            const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+            const uint32_t pos = basepos[key[k] >> lshift] + atomicAdd(&h[key[k] >> lshift], 1u);
             if (perm) perm[pos] = t;                  // single-level mode: this IS the final order
-            else tmp_key[pos] = key;
-            tmp_rec[pos] = make_float4(q[3 * t], q[3 * t + 1], q[3 * t + 2], __uint_as_float(t));
+            else tmp_key[pos] = key[k];
+            tmp_rec[pos] = make_float4(qv[k][0], qv[k][1], qv[k][2], __uint_as_float(t));
         }
     }
 }
