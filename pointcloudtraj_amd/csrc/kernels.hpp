@@ -547,12 +547,6 @@ __global__ __launch_bounds__(256) void merge_mask_kernel(const double *__restric
     cand[i] = (d == d2_best[i] && d < __builtin_huge_val() && ix <= 0x7FFFFFFEu) ? (int32_t)ix : 0x7FFFFFFF;
 }
 
-__global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t *__restrict__ p, uint32_t v, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 // one 256-thread block per query folds the per-block partials (loads issued back to back,
 // compared afterwards); adds the shard's index base
 __global__ __launch_bounds__(256) void nn_reduce_partials_kernel(const double *__restrict__ part_d2,
@@ -652,27 +646,9 @@ __global__ __launch_bounds__(256) void count_stream_kernel(const float *__restri
     }
 }
 
-// lidar crop: indices within r of ONE centre.  Two passes share this kernel: flags -> scan is
-// avoided by a wave-aggregated atomic cursor; the host sorts the (unordered) result ascending.
-__global__ __launch_bounds__(256) void radius_collect_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                             const float *__restrict__ z, uint32_t n, double qx, double qy,
-                                                             double qz, double r2, uint32_t index_base,
-                                                             uint32_t *__restrict__ out, uint32_t cap,
-                                                             uint32_t *__restrict__ cursor)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const bool hit = dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz) <= r2;
-        if (hit) {
-            const uint32_t pos = atomicAdd(cursor, 1u);
-            if (pos < cap) out[pos] = i + index_base;
-        }
-    }
-}
-
-// Order-preserving crop (lidar sensor: camera_sensor.cpp:133-145 radiusSearch + PointCloud(cloud, indices)).  The
-// one-counter kernel above serialises on its cursor (same-address atomics: ~12 ns each, 20 K hits = 0.25 ms) and
-// returns arrival order; this pair keeps insertion order and has no contended atomic:
+// Order-preserving crop (lidar sensor: camera_sensor.cpp:133-145 radiusSearch + PointCloud(cloud, indices)).  A first
+// version appended hits through one global cursor: it serialised on that address (~12 ns per hit, 20 K hits = 0.25 ms) and
+// returned arrival order; this pair keeps insertion order and has no contended atomic:
 //   crop_count_kernel    hits per 1024-point tile                                    (12 B/point read)
 //   (scan_tile_sums_kernel, one block: exclusive scan of the tile counts)
 //   crop_scatter_kernel  recompute the test, rank inside the tile, write {index, d2, x, y, z}  (12 B/point + 32 B/hit)
