@@ -588,3 +588,22 @@ def test_brute_force_with_bulk_duplicates(E, oracle):
     i2, d2 = c.nn(q, E.ALGO_GRID)
     assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
     c.close()
+
+
+@pytest.mark.gpu
+def test_four_million_query_batch(E, oracle):
+    """A batch four times the bench's: 4,194,304 queries against 1 M points through the sorted cell-pruned path; every reported
+    d2 is the fp64 distance to the reported point, a slice agrees with the brute-force path and the exhaustive oracle."""
+    pts = synth.uniform_points(91, 1_000_000, 0, 60)
+    q = synth.uniform_points(92, 1 << 22, -1, 61)
+    c = make_cloud(E, pts, grid=True)
+    ig, dg = c.nn(q, E.ALGO_GRID)
+    P = pts[ig.astype(np.int64)].astype(np.float64) - q.astype(np.float64)
+    s = P[:, 0] * P[:, 0]; s = s + P[:, 1] * P[:, 1]; s = s + P[:, 2] * P[:, 2]
+    assert np.array_equal(s, dg)
+    sl = slice(3_000_000, 3_020_000)
+    ib, db = c.nn(q[sl], E.ALGO_STREAM)
+    assert np.array_equal(ib, ig[sl]) and np.array_equal(db, dg[sl])
+    bi, bd = oracle.brute_nearest(pts, q[-32:])
+    assert np.array_equal(dg[-32:], bd) and np.array_equal(ig[-32:].astype(np.int64), bi.astype(np.int64))
+    c.close()
