@@ -281,7 +281,7 @@ int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64
 
 // Streaming kernels are grid-stride: at most 4 blocks of 256 threads per CU (16 waves per CU),
 // so the whole grid is resident in ONE round whatever the kernel's register count -- a grid of
-// 8 blocks per CU ran as 7 + 1 rounds at 66 VGPRs and cost almost 2x (profiles/r01_a).
+// 8 blocks per CU ran as 7 + 1 rounds at 66 VGPRs and cost almost 2x.
 int stream_blocks(int64_t n)
 {
     const char *e = std::getenv("PCT_STREAM_BLOCKS");      // tuning knob for scripts/probe.py

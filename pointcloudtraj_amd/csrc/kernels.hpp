@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void nn_stream_kernel(const float *__restrict_
 // -------------------------------------------------------------------------------------
 // fp32 filter + exact fp64 recheck, LDS-staged (the default brute-force path for Q > 4).
 //
-// Measured on MI355X (profiles/r01_c): an fp64 vector op costs ~8 cycles per wave and a plain
+// Measured on MI355X: an fp64 vector op costs ~8 cycles per wave and a plain
 // fp32 op ~4; only the packed v_pk_{add,mul,fma}_f32 forms reach the fp32 peak (2 lanes-worth per
 // 4 cycles).  The all-fp64 kernel above needs 12 slow ops per (point, query) pair and tops out at
 // 1.8e12 pairs/s.  Exactness only matters for the few points that can win, so:
@@ -954,11 +954,11 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float *__restri
 
 // Query binning for the cell-pruned kernels: a counting sort of the batch by coarse cell
 // ((cx,cy,cz) >> shift, x fastest) so that neighbouring lanes walk neighbouring cells and
-// share cache lines.  Random 1M-query batches ran 2.5x faster pre-sorted (profiles/r01_b).
+// share cache lines.  Random 1M-query batches ran 2.5x faster pre-sorted.
 // Bin order = (y-strip, z, y inside the strip, x): walking the batch in this order sweeps a strip
 // of `strip` bin rows through all z before moving to the next strip, so the planes a stretch of
 // queries re-uses (z-1, z, z+1) are a strip wide, not a whole plane wide, and stay inside one
-// XCD's 4 MiB L2 (a full-plane sweep re-fetched every plane ~3x: profiles/r01_d).
+// XCD's 4 MiB L2 (a full-plane sweep re-fetched every plane ~3x, measured).
 struct BinDesc { int shift, bx, by, bz, strip; uint32_t nbins; };
 
 __device__ __forceinline__ uint32_t query_bin(const GridDesc &G, const BinDesc &B, float qx, float qy, float qz)
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void query_bin_scatter_kernel(const uint32_t *
 
 // Counting sort of the batch on LDS histograms, one or two levels (replaces the global-atomic version
 // above for large batches: 2 M scattered device-scope atomics ran at ~20 G/s = 100 us per 1 M
-// queries, profiles/r01_d).  key = bin >> key_shift (< 2^20); level 1 = key >> 10 (<= 1024
+// queries).  key = bin >> key_shift (< 2^20); level 1 = key >> 10 (<= 1024
 // buckets), level 2 = key & 1023 inside a bucket.  Global atomics are one per (block, non-empty
 // bucket); everything else is LDS atomics and coalesced traffic.
 constexpr int kSortBuckets = 1024;
@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
                 uint32_t p1 = 0;
                 // one z-plane (3 rows) at a time: the first 4 points of each row are requested together
                 // (12 independent 16-byte loads in flight), rows longer than 4 continue 4 at a time.
-                // The kernel is bound by dependent memory round trips, not by arithmetic (profiles/r01_d).
+                // The kernel is bound by dependent memory round trips, not by arithmetic.
 #pragma unroll
                 for (int g = 0; g < 3; g++) {
                     float4 P[3][4];
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
 // Cooperative form of the cell-pruned NN: EIGHT lanes per query (8 queries per wave).
 //
 // The lane-per-query kernel above is bound by the vector L1's address path, not by arithmetic or
-// DRAM (profiles/r01_d: ~150 L1 accesses per query, texture-address unit busy 65 % of the kernel):
+// DRAM (measured: ~150 L1 accesses per query, texture-address unit busy 65 % of the kernel):
 // a lane reading the 6 points of a run one after the other issues 6 separate 16-byte accesses to
 // the SAME 128-byte line.  Here the 8 lanes of a group read 8 consecutive points of a run with one
 // coalesced 128-byte access, the 9 rows' cell_start entries are fetched by 9 different lanes at
