@@ -439,8 +439,9 @@ private:
     {
         int64_t done = 0;
         while (done < iterations) {
-            if (spec_k_ <= 1) { growOnce(refine); done++; continue; }
-            done += growBatch((int)std::min<int64_t>(spec_k_, iterations - done), refine);
+            if (spec_k_ <= 1 && !fused_ok_) { growOnce(refine); done++; continue; }      // three single queries per iteration
+            // (with the fused kernel even K = 1 is one launch per iteration instead of three)
+            done += growBatch((int)std::min<int64_t>(std::max(spec_k_, 1), iterations - done), refine);
         }
     }
 
