@@ -632,12 +632,16 @@ InflateParams to_dev(const pct_inflate_params *p)
 }
 
 // pts64 (device, Q x 3) -> radius/idx/d2 in the cloud's workspaces
-int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_t s)
+// d_pts: the planner points (device-visible), default the staging buffer; d_out != nullptr: results as records in host-mapped memory
+int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_t s, const double *d_pts = nullptr, ExpressOut *d_out = nullptr)
 {
     const InflateParams P = to_dev(p);
-    inflate_prologue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, c->d_pts64, (uint32_t)Q, c->d_q, c->d_skip);
+    inflate_prologue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, d_pts ? d_pts : c->d_pts64, (uint32_t)Q, c->d_q, c->d_skip);
     if (c->count > 0) PCTCHK(nn_dev(c, PCT_ALGO_AUTO, c->d_q, Q, c->d_idx, c->d_d2, s));
-    inflate_epilogue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, c->d_radius);
+    if (d_out)
+        inflate_epilogue_out_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, d_out);
+    else
+        inflate_epilogue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, c->d_radius);
     HIPCHK(hipGetLastError());
     return PCT_OK;
 }
@@ -1298,6 +1302,17 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
         return PCT_OK;
     }
     PCTCHK(pct_cloud_reserve_queries(c, Q));
+    if (Q <= kExpressMaxQ) {      // small batch on an un-indexed (e.g. rolling) cloud: brute-force kernels, arguments and results in mapped memory
+        std::memcpy(c->h_xin, pts, sizeof(double) * 3 * Q);
+        PCTCHK(inflate_dev(c, p, Q, g_stream, c->d_xin, c->d_xout));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int64_t i = 0; i < Q; i++) {
+            radius[i] = c->h_xout[i].radius;
+            if (idx) idx[i] = c->h_xout[i].idx;
+            if (d2) d2[i] = c->h_xout[i].d2;
+        }
+        return PCT_OK;
+    }
     HIPCHK(hipMemcpyAsync(c->d_pts64, pts, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
     PCTCHK(inflate_dev(c, p, Q, g_stream));
     HIPCHK(hipMemcpyAsync(radius, c->d_radius, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
@@ -1357,7 +1372,7 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
         if (traj->orders[i] < 0 || traj->orders[i] > kMaxBezierOrder || 3 * (traj->orders[i] + 1) > traj->row_stride)
             return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
     const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
-    if (c->has_grid && c->count > 0 && ncoef + (size_t)traj->nseg <= 3 * (size_t)kExpressMaxQ - 64) {
+    if (ncoef + (size_t)traj->nseg <= 3 * (size_t)kExpressMaxQ - 64) {
         // express: the host enumerates the sample times (sim_planning_demo.cpp:729-771, the same sequential fp64 additions as
         // bezier_samples_kernel), then ONE launch evaluates, inflates and searches every sample (bezier_block_kernel)
         double *hd = c->h_xin;                                  // [coef | seg_time | sample_t]
@@ -1389,12 +1404,19 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
         const bool fits = n <= room || room == cap;             // more samples than one express launch holds: staged path below
         if (fits && m > 0) {
             if (!c->h_bpos) PCTCHK(mapped_alloc(&c->h_bpos, &c->d_bpos, (size_t)3 * kExpressMaxQ));
-            const double reach = p->max_radius + p->search_margin;
-            const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
-            bezier_block_kernel<<<(int)m, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, (int)traj->row_stride,
-                                                               c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg, c->d_xin + ncoef + traj->nseg,
-                                                               stop_d2, (uint32_t)c->index_base, c->d_xout, c->d_bpos);
-            HIPCHK(hipGetLastError());
+            if (c->has_grid && c->count > 0) {        // indexed cloud: everything in ONE launch
+                const double reach = p->max_radius + p->search_margin;
+                const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
+                bezier_block_kernel<<<(int)m, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, (int)traj->row_stride,
+                                                                   c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg, c->d_xin + ncoef + traj->nseg,
+                                                                   stop_d2, (uint32_t)c->index_base, c->d_xout, c->d_bpos);
+                HIPCHK(hipGetLastError());
+            } else {                                      // un-indexed (rolling) cloud: evaluate, then the brute-force inflation; still no copies
+                PCTCHK(pct_cloud_reserve_queries(c, m));
+                bezier_eval_kernel<<<ceil_div(m, 128), 128, 0, g_stream>>>(c->d_xin, (int)traj->row_stride, c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg,
+                                                                           c->d_xin + ncoef + traj->nseg, (int)m, c->d_pts64, c->d_bpos);
+                PCTCHK(inflate_dev(c, p, m, g_stream, c->d_pts64, c->d_xout));
+            }
             HIPCHK(hipStreamSynchronize(g_stream));
         }
         if (fits) {

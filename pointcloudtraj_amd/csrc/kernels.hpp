@@ -1897,6 +1897,26 @@ __global__ __launch_bounds__(256) void inflate_epilogue_kernel(InflateParams P, 
     radius[i] = r < P.max_radius ? r : P.max_radius;
 }
 
+// the same epilogue writing one {d2, radius, idx} record per point into host-mapped memory (small batches: the host reads the
+// results after one stream sync instead of issuing three device-to-host copies)
+__global__ __launch_bounds__(256) void inflate_epilogue_out_kernel(InflateParams P, uint32_t n, const unsigned char *__restrict__ skip,
+                                                                   int cloud_empty, const uint32_t *__restrict__ idx,
+                                                                   const double *__restrict__ d2, ExpressOut *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (skip[i] || cloud_empty) {
+        out[i].radius = P.max_radius - P.search_margin;
+        out[i].idx = kNoIndex;
+        out[i].d2 = __builtin_huge_val();
+        return;
+    }
+    const double r = sqrt(d2[i]) - P.search_margin;
+    out[i].radius = r < P.max_radius ? r : P.max_radius;
+    out[i].idx = idx[i];
+    out[i].d2 = d2[i];
+}
+
 // Block-wide winner: every thread passes its (d2, index) and gets back the block's best.
 __device__ __forceinline__ void block_argmin256(double &d, uint32_t &i, double *s_d, uint32_t *s_i)
 {
@@ -2182,6 +2202,31 @@ __global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const fl
         out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
+    }
+}
+
+// getPosFromBezier for host-enumerated samples (segment, t), one thread per sample, the arithmetic of bezier_samples_kernel;
+// positions go to device memory for the inflation kernels and to host-mapped memory for the caller
+__global__ __launch_bounds__(128) void bezier_eval_kernel(const double *__restrict__ coef, int row_stride, const double *__restrict__ seg_time,
+                                                          const uint32_t *__restrict__ orders, const uint32_t *__restrict__ sample_seg,
+                                                          const double *__restrict__ sample_t, int n, double *__restrict__ pos_dev,
+                                                          double *__restrict__ pos_mapped)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const int seg = (int)sample_seg[s];
+    const int order = (int)orders[seg], m = order + 1;
+    const double T = seg_time[seg];
+    const double u = sample_t[s] / T;
+    const double *c = coef + (size_t)seg * row_stride;
+    double binom[kMaxBezierOrder + 1];
+    binom[0] = 1.0;
+    for (int j = 1; j <= order; j++) binom[j] = floor(binom[j - 1] * (double)(order - j + 1) / (double)j + 0.5);
+    for (int d = 0; d < 3; d++) {
+        double acc = 0.0;
+        for (int j = 0; j < m; j++) acc += binom[j] * c[d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+        pos_dev[3 * s + d] = acc * T;
+        pos_mapped[3 * s + d] = acc * T;
     }
 }
 
