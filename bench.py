@@ -383,6 +383,32 @@ def main():
         vm.close()
         del d_pts
 
+    if a.replan_probe and world == 1:
+        # config C4 on ONE card: the whole 100 M-point cloud (seed 6, [0,200)^3) resident, Q = 4096 (seed 7), host buffers
+        p4 = synth.uniform_points(6, 100_000_000, 0.0, 200.0)
+        q4 = synth.uniform_points(7, 4096, 0.0, 200.0)
+        with E.Cloud(len(p4)) as c4:
+            t1 = time.perf_counter()
+            c4.set_input(p4)
+            t2 = time.perf_counter()
+            c4.build_grid()
+            E.sync()
+            t3 = time.perf_counter()
+            c4.nn(q4, E.ALGO_GRID)
+            ts = []
+            for _ in range(5):
+                t4 = time.perf_counter()
+                i4, d4 = c4.nn(q4, E.ALGO_GRID)
+                ts.append(1e3 * (time.perf_counter() - t4))
+            t5 = time.perf_counter()
+            ib, db = c4.nn(q4[:512], E.ALGO_STREAM)
+            t6 = time.perf_counter()
+        out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted), 4096 NN queries, host buffers",
+                           "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_batch_ms": float(np.median(ts)),
+                           "brute_force_512_queries_ms": 1e3 * (t6 - t5), "brute_force_pair_evals_per_s": 512 * 1e8 / (t6 - t5),
+                           "indexed_equals_brute_force": bool(np.array_equal(ib, i4[:512]) and np.array_equal(db, d4[:512]))}
+        del p4
+
     if a.cpu_queries > 0 and world == 1:
         ncpu = a.cpu_points or a.points
         base, cpu_idx, cq = cpu_baseline(lambda: local_pts[:ncpu], ncpu, q_host, min(a.cpu_queries, Q))
