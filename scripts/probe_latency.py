@@ -39,4 +39,4 @@ for sgm in range(3):
             coef[sgm, d * 7 + j] = (40.0 + 4.0 * (sgm + j / 6.0) + (0.3 if d == 1 else 0.0))
 print("bezier_check 99 samples (indexed cloud, one launch): %.1f / %.1f us" % lat(lambda: c.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128)))
 c2 = E.Cloud(len(pts)); c2.set_input(pts[:5_000_000])
-print("bezier_check 99 samples (un-indexed 5 M cloud, brute force, staged): %.1f / %.1f us" % lat(lambda: c2.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128), 50))
+print("bezier_check 99 samples (un-indexed 5 M cloud, brute force, mapped I/O): %.1f / %.1f us" % lat(lambda: c2.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128), 50))
