@@ -84,8 +84,24 @@ int pct_cloud_upload_fields(pct_cloud *c, const void *data, int64_t n, int64_t p
 /* Same, from three device arrays (already SoA, e.g. produced on the GPU). */
 int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n);
 /* Rolling map: append n points, overwriting the oldest once capacity is reached (ring).
- * Index of a point = its slot in the ring.  Drops any grid. */
+ * Index of a point = its slot in the ring.  Drops any cell-sorted grid; updates the rolling-map index in place. */
 int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes);
+
+/* Rolling-map index (config C5: the obstacle map is a sliding window fed one sensor frame at a time, where the reference
+ * rebuilds its search tree per frame -- safeRegionRrtStar::setInput, Planner/src/corridor_finder.cpp:93-99 called from
+ * rcvPointCloudCallBack, Planner/src/sim_planning_demo.cpp:159-167).  After this call pct_cloud_append_aos no longer drops an
+ * index: it retires the points it overwrites from a world-anchored bucket table and files the new frame, in place, and
+ * pct_nn_batch / pct_inflate_batch / pct_bezier_check / pct_ctrl_points_check / the replan plan search that table (ALGO_AUTO
+ * and ALGO_GRID; ALGO_STREAM still scans the whole window).  Results are the same as on any other cloud: exact fp64
+ * distances, lowest ring slot on ties.  cell_size <= 0: chosen from the first data (about 6 points per cell at capacity);
+ * extent (may be NULL): the window's size per axis, when the caller knows it (e.g. the sensing range) -- the table is then
+ * allocated at once.  Memory: 512 B per bucket (32 records), buckets = the extent / cell_size per axis plus a quarter,
+ * rounded up to powers of two; a cell holding more than 32 points spills to a queue every query scans exhaustively
+ * (pct_cloud_ring_info reports its length).  Not available for small (host-mapped) clouds; excludes pct_cloud_build_grid. */
+int pct_cloud_ring_index(pct_cloud *c, float cell_size, const float extent[3]);
+int pct_cloud_ring_drop(pct_cloud *c);
+int pct_cloud_has_ring_index(const pct_cloud *c);
+int pct_cloud_ring_info(pct_cloud *c, int32_t dims[3], double *cell_size, int64_t *overflow_entries);
 
 /* Build / drop the uniform-cell index used by PCT_ALGO_GRID.  cell_size <= 0 picks one from
  * the bounding box and point count (about `pct` points per cell). */
@@ -163,6 +179,16 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
                      int64_t *first_hit, int64_t *nsamples,
                      int64_t cap, double *pos, double *radius, double *d2, uint32_t *idx);
 
+/* Control-point check (SURVEY.md 3.3, config C5's build extension): the threshold test of checkTrajPtCol
+ * (Planner/src/corridor_finder.cpp:412-416) applied to the raw control points of the committed trajectory in world units --
+ * control point j of segment i is polycoef[i][d*(n+1)+j] * seg_time[i] (layout Planner/src/traj_optimizer.cpp:739-751), the
+ * point the optimizer's cone constraint keeps inside corridor sphere i (Planner/src/traj_optimizer.cpp:624-648).  Segments
+ * from the one holding t_start on (the segment search of checkSafeTrajectory, sim_planning_demo.cpp:735-741), j ascending.
+ * first_hit = index into that list of the first control point with radiusSearch(point) < 0, -1 when none; nctrl = its length;
+ * optional per-point outputs (capacity cap): pos (cap x 3), radius, d2, idx. */
+int pct_ctrl_points_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflate_params *p, double t_start,
+                          int64_t *first_hit, int64_t *nctrl, int64_t cap, double *pos, double *radius, double *d2, uint32_t *idx);
+
 /* ---- batch queries, DEVICE buffers, asynchronous on `stream` (a hipStream_t; NULL = HIP's null
  * stream, as in any HIP call -- that is also PyTorch's default stream).  Every kernel of the batch is
  * ordered on that stream and nothing else, so work the caller queues behind it (a collective, a copy)
@@ -179,11 +205,39 @@ int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const 
 /* make sure workspaces for batches up to Q exist (call before capturing a graph) */
 int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q);
 
-/* ---- hipGraph-captured fixed-shape batch (config C5: 20 Hz replan) ----------------------- */
-/* Captures H2D(queries) -> NN kernels -> D2H(idx,d2) once; pct_plan_run replays it. */
+/* ---- hipGraph-captured fixed-shape batches (config C5: 20 Hz replan) ----------------------- */
+/* Captures H2D(queries) -> NN kernels -> D2H(idx,d2) once; pct_plan_run replays it.
+ * A plan belongs to its cloud and must be destroyed before it.  The captured kernels hold the cloud's point count, index and
+ * workspace pointers; whenever one of them changes (upload / append on a cloud without the ring index, pct_cloud_build_grid /
+ * drop_grid, pct_cloud_ring_index, a larger batch that grows the workspaces) the next run captures the graph again by itself
+ * (one capture costs a few hundred microseconds).  Appends on a ring-indexed cloud change none of them. */
 int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out);
 int pct_plan_run(pct_plan *p, const float *q, uint32_t *idx, double *d2);
 int pct_plan_destroy(pct_plan *p);
+
+/* The whole query side of one replan tick as ONE captured graph (config C5; the reference's chain is
+ * rcvPointCloudCallBack -> checkSafeTrajectory, Planner/src/sim_planning_demo.cpp:159-178, 729-781, next to
+ * SafeRegionEvaluate's re-check of the corridor nodes, Planner/src/corridor_finder.cpp:829-835):
+ *   arguments in (corridor node centres, trajectory, sample times) -> ONE kernel with a block per planner point: sphere
+ *   inflation of every corridor node, getPosFromBezier + inflation of every sample of the committed trajectory, inflation of
+ *   every control point (pct_ctrl_points_check) -> first colliding sample / control point -> results out.
+ * The cloud needs an index: the rolling-map one (pct_cloud_ring_index; appends then never invalidate the plan) or the
+ * cell-sorted one (pct_cloud_build_grid; re-captured after a rebuild).  Capacities are fixed at creation: at most max_nodes
+ * corridor nodes, max_samples trajectory samples (further ones are counted in nsamples but not evaluated), max_segments
+ * segments (13 control points each).  want_nn != 0: exact nearest neighbour for every point (idx / d2 outputs meaningful);
+ * 0: the search may stop once everything unseen is beyond max_radius + search_margin (radii identical, idx / d2 then only
+ * say "some point at least this near"). */
+typedef struct pct_replan_out {
+    double *node_radius; uint32_t *node_idx; double *node_d2;                      /* n_nodes each; any may be NULL */
+    double *sample_pos, *sample_radius, *sample_d2; uint32_t *sample_idx;          /* up to max_samples (pos: x3); any may be NULL */
+    double *ctrl_pos, *ctrl_radius, *ctrl_d2; uint32_t *ctrl_idx;                  /* nctrl (pos: x3); any may be NULL */
+    int64_t nsamples, first_hit_sample;                                            /* filled: as pct_bezier_check */
+    int64_t nctrl, first_hit_ctrl;                                                 /* filled: as pct_ctrl_points_check */
+} pct_replan_out;
+int pct_plan_create_replan(pct_cloud *c, int32_t max_nodes, int32_t max_samples, int32_t max_segments, pct_plan **out);
+/* traj may be NULL (corridor nodes only) */
+int pct_plan_replan_run(pct_plan *p, const pct_inflate_params *prm, const double *nodes, int64_t n_nodes, const pct_bezier_traj *traj,
+                        double t_start, double stop_time, double dt, int want_nn, pct_replan_out *out);
 
 /* ---- measurement hooks (bench.py): HIP events recorded on the stream the kernels ran on.
  * pct_last_kernel_ms: the last batch's DOMINANT kernel alone (nn_grid_kernel, nn_tile_filter_kernel

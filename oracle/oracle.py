@@ -270,6 +270,75 @@ def brute_count(xyz, q, r):
     return cnt
 
 
+def brute_nearest_mt(xyz, q, threads: int = 0):
+    """brute_nearest with the queries split over host threads (ctypes releases the GIL): same results"""
+    import concurrent.futures as cf
+    q = _f32c(q).reshape(-1, 3)
+    xyz = _f32c(xyz).reshape(-1, 3)
+    threads = threads or min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32)
+    threads = max(1, min(threads, len(q)))
+    if threads == 1:
+        return brute_nearest(xyz, q)
+    parts = np.array_split(np.arange(len(q)), threads)
+    with cf.ThreadPoolExecutor(threads) as ex:
+        res = list(ex.map(lambda ix: brute_nearest(xyz, q[ix]), parts))
+    return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+
+def inflate_brute(xyz, start, sample_range, search_margin, max_radius, pts, threads: int = 0):
+    """radiusSearch (corridor_finder.cpp:113-133) over an exhaustive nearest neighbour: (radius, idx, d2) for (n,3) fp64 points;
+    early-out rows give max_radius - search_margin, idx -1, d2 inf"""
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 3)
+    dx, dy, dz = pts[:, 0] - start[0], pts[:, 1] - start[1], pts[:, 2] - start[2]
+    far = np.sqrt(dx * dx + dy * dy + dz * dz) > sample_range + max_radius
+    idx, d2 = brute_nearest_mt(xyz, pts.astype(np.float32), threads)
+    rad = np.minimum(np.sqrt(d2) - search_margin, max_radius)
+    skip = far | (len(np.asarray(xyz).reshape(-1, 3)) == 0)
+    rad = np.where(skip, max_radius - search_margin, rad)
+    return rad, np.where(skip, -1, idx), np.where(skip, np.inf, d2)
+
+
+def replan_tick(xyz, start, sample_range, search_margin, max_radius, nodes, polycoef, seg_time, orders, t_start, stop_time, dt=0.02,
+                cap=4096, threads: int = 0):
+    """CPU statement of one replan tick's query side: corridor-node inflation (corridor_finder.cpp:829-835), the sampled Bezier
+    check (sim_planning_demo.cpp:729-781) and the control-point check against the cloud `xyz`, exhaustively."""
+    L = port_lib()
+    polycoef = np.ascontiguousarray(polycoef, np.float64)
+    seg_time = np.ascontiguousarray(seg_time, np.float64)
+    orders = np.ascontiguousarray(orders, np.int32)
+    seg = np.zeros(cap, np.int32)
+    tt = np.zeros(cap, np.float64)
+    pos = np.zeros((cap, 3), np.float64)
+    ns = L.ocor_bezier_samples(polycoef, polycoef.shape[1], seg_time, orders, len(seg_time), float(t_start), float(stop_time), float(dt),
+                               seg, tt, pos.reshape(-1), cap)
+    n = min(ns, cap)
+    # control points in world units, segments from the one holding t_start on (the segment search of checkSafeTrajectory)
+    t_s, first = float(t_start), 0
+    while first < len(seg_time):
+        if t_s > seg_time[first] and first + 1 < len(seg_time):
+            t_s -= seg_time[first]
+            first += 1
+        else:
+            break
+    ctrl = []
+    for i in range(first, len(seg_time)):
+        m = int(orders[i]) + 1
+        for j in range(m):
+            ctrl.append([polycoef[i, j] * seg_time[i], polycoef[i, m + j] * seg_time[i], polycoef[i, 2 * m + j] * seg_time[i]])
+    ctrl = np.asarray(ctrl, np.float64).reshape(-1, 3)
+    nodes = np.ascontiguousarray(nodes, np.float64).reshape(-1, 3)
+    allp = np.concatenate([nodes, pos[:n], ctrl])
+    rad, idx, d2 = inflate_brute(xyz, start, sample_range, search_margin, max_radius, allp, threads)
+    a, b = len(nodes), len(nodes) + n
+
+    def first_neg(r):
+        w = np.nonzero(r < 0.0)[0]
+        return int(w[0]) if len(w) else -1
+    return dict(node_radius=rad[:a], node_idx=idx[:a], node_d2=d2[:a], nsamples=int(ns), sample_pos=pos[:n], sample_radius=rad[a:b],
+                sample_idx=idx[a:b], sample_d2=d2[a:b], first_hit_sample=first_neg(rad[a:b]), nctrl=len(ctrl), ctrl_pos=ctrl,
+                ctrl_radius=rad[b:], ctrl_idx=idx[b:], ctrl_d2=d2[b:], first_hit_ctrl=first_neg(rad[b:]))
+
+
 class _CorParams(C.Structure):
     _fields_ = [("start", C.c_double * 3), ("sample_range", C.c_double), ("search_margin", C.c_double),
                 ("max_radius", C.c_double), ("cloud_empty", C.c_int)]

@@ -21,6 +21,7 @@
 #include "../../include/pct_engine.h"
 #include "engine_internal.hpp"
 #include "kernels.hpp"
+#include "ring.hpp"
 
 using namespace pct;
 
@@ -169,9 +170,30 @@ struct pct_cloud {
     bool host_work = false;        // last batch's work is known on the host (streaming kernel)
     uint64_t host_points = 0;
     bool capturing = false;
+    // bumped whenever something a captured plan baked in goes away or changes meaning: workspace reallocation, a new point
+    // count on a cloud without the ring index, grid build / drop, ring-index (re)configuration
+    uint64_t generation = 1;
+    // rolling-map index (ring.hpp): bucket table that appends update in place
+    bool ring_on = false, ring_ready = false;
+    float ring_cell_req = 0.0f;
+    float ring_extent_req[3] = { 0.0f, 0.0f, 0.0f };
+    RingDesc R{};
+    size_t ring_cells = 0;
+    uint2 *ring_ht = nullptr;
+    float4 *ring_slots = nullptr, *ring_ovf = nullptr;
+    uint32_t *ring_where = nullptr;
+    RingState *ring_st = nullptr;
+    struct ReplanCtx *rp = nullptr;              // lazily created context of the un-captured fused planner batch
 };
 
+struct ReplanCtx;
+void replan_ctx_free(ReplanCtx *x);
+
 struct pct_plan {
+    int kind = 0;                                // 0 = NN batch, 1 = fused replan batch
+    uint64_t generation = 0;                     // the cloud's generation the graph was captured at
+    int algo = 0;
+    ReplanCtx *rx = nullptr;
     pct_cloud *c = nullptr;
     int64_t Q = 0;
     float *h_q = nullptr;
@@ -245,7 +267,11 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
     return PCT_OK;
 }
 
-void drop_grid(pct_cloud *c) { c->has_grid = false; }
+void drop_grid(pct_cloud *c)
+{
+    if (c->has_grid) c->generation++;
+    c->has_grid = false;
+}
 
 // host AoS -> device SoA slots [dst0, dst0+n)
 int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64_t dst0)
@@ -526,6 +552,8 @@ int nn_stream_filtered(pct_cloud *c, const float *d_qf, int64_t Q, uint32_t *d_i
     return PCT_OK;
 }
 
+int ring_nn_dev(pct_cloud *c, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s);
+
 int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t s)
 {
     if (Q == 0) return PCT_OK;
@@ -535,6 +563,7 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         HIPCHK(hipGetLastError());
         return PCT_OK;
     }
+    if (c->ring_ready && (algo == PCT_ALGO_AUTO || algo == PCT_ALGO_GRID)) return ring_nn_dev(c, d_q, Q, d_idx, d_d2, s);   // rolling-map index
     if (algo == PCT_ALGO_AUTO) algo = c->has_grid ? PCT_ALGO_GRID : PCT_ALGO_STREAM;
     if (algo == PCT_ALGO_GRID) {
         if (!c->has_grid) return fail(PCT_ERR_INVALID, "PCT_ALGO_GRID without a grid (call pct_cloud_build_grid)");
@@ -647,6 +676,8 @@ int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_
 }
 
 }  // namespace
+
+#include "ring_host.inc"
 
 // ======================================================================================
 //  C ABI
@@ -767,6 +798,8 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
+    dev_free(c->ring_ht); dev_free(c->ring_slots); dev_free(c->ring_ovf); dev_free(c->ring_where); dev_free(c->ring_st);
+    replan_ctx_free(c->rp);
     dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -794,7 +827,7 @@ int pct_cloud_upload_aos(pct_cloud *c, const void *pts, int64_t n, int64_t strid
     HIPCHK(hipStreamSynchronize(g_stream));    // the host buffer is the caller's again
     c->count = n;
     c->ring_next = n % std::max<int64_t>(c->cap, 1);
-    return PCT_OK;
+    return after_replace(c);
 }
 
 // sensor_msgs/PointCloud2 (rcvPointCloudCallBack, sim_planning_demo.cpp:159-167): a byte blob of `n` records of
@@ -830,7 +863,7 @@ int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, c
     }
     c->count = n;
     c->ring_next = n % std::max<int64_t>(c->cap, 1);
-    return PCT_OK;
+    return after_replace(c);
 }
 
 int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes)
@@ -839,6 +872,7 @@ int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t strid
     if (n > c->cap) return fail(PCT_ERR_CAPACITY, "appending %lld points to a ring of %lld", (long long)n, (long long)c->cap);
     if (n == 0) return PCT_OK;
     drop_grid(c);
+    if (c->ring_ready) return ring_append(c, pts, n, stride_bytes);     // rolling-map index: updated in place
     const int64_t first = std::min(n, c->cap - c->ring_next);
     PCTCHK(upload_range(c, pts, first, stride_bytes, c->ring_next));
     HIPCHK(hipStreamSynchronize(g_stream));   // the staging buffer is reused by the wrapped part
@@ -848,7 +882,7 @@ int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t strid
     }
     c->ring_next = (c->ring_next + n) % c->cap;
     c->count = std::min(c->cap, c->count + n);
-    return PCT_OK;
+    return after_replace(c);
 }
 
 int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
@@ -862,6 +896,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
     c->qcap = 0;
+    c->generation++;                    // captured plans hold these pointers
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
     PCTCHK(dev_alloc(&c->d_r, q));
     PCTCHK(dev_alloc(&c->d_q64, 3 * q));
@@ -917,6 +952,7 @@ int pct_cloud_grid_info(const pct_cloud *c, int32_t dims[3], float *cell_size, f
 int pct_cloud_build_grid(pct_cloud *c, float cell_size)
 {
     if (!c) return fail(PCT_ERR_INVALID, "null cloud");
+    if (c->ring_on) return fail(PCT_ERR_INVALID, "this cloud keeps the rolling-map index (pct_cloud_ring_index); drop it before building the cell-sorted one");
     drop_grid(c);
     const int64_t n = c->count;
     if (n == 0) return fail(PCT_ERR_EMPTY, "cannot index an empty cloud");
@@ -1030,6 +1066,7 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     }
     c->B = B;
     c->has_grid = true;
+    c->generation++;
     return PCT_OK;
 }
 
@@ -1051,6 +1088,16 @@ int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_
 {
     if (!c || Q < 0 || (Q > 0 && (!q || !idx || !d2))) return fail(PCT_ERR_INVALID, "bad nn_batch arguments");
     if (Q == 0) return PCT_OK;
+    if (Q <= kExpressMaxQ && c->ring_ready && c->count > 0 && (algo == PCT_ALGO_AUTO || algo == PCT_ALGO_GRID)) {
+        // small batch on the rolling map: one launch, a block per query, arguments/results in mapped memory
+        for (int64_t i = 0; i < 3 * Q; i++) c->h_xin[i] = (double)q[i];
+        ring_batch_kernel<false><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), InflateParams{}, nullptr, c->d_xin, (double)INFINITY, (uint32_t)c->index_base,
+                                                               nullptr, nullptr, nullptr, c->d_xout);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+        for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
+        return PCT_OK;
+    }
     if (Q <= kExpressMaxQ && c->has_grid && c->count > 0 && (algo == PCT_ALGO_AUTO || algo == PCT_ALGO_GRID)) {
         // small batch on an indexed cloud: one launch, a block per query, arguments/results in mapped memory
         for (int64_t i = 0; i < 3 * Q; i++) c->h_xin[i] = (double)q[i];
@@ -1286,6 +1333,33 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
 {
     if (!c || !p || Q < 0 || (Q > 0 && (!pts || !radius))) return fail(PCT_ERR_INVALID, "bad inflate arguments");
     if (Q == 0) return PCT_OK;
+    if (c->ring_ready) {          // rolling map: a block per point over the bucket table; small batches through mapped memory
+        const double reach = p->max_radius + p->search_margin;
+        const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
+        if (Q <= kExpressMaxQ) {
+            std::memcpy(c->h_xin, pts, sizeof(double) * 3 * Q);
+            ring_batch_kernel<true><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), to_dev(p), nullptr, c->d_xin, stop_d2, (uint32_t)c->index_base, nullptr, nullptr,
+                                                                  nullptr, c->d_xout);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(g_stream));
+            for (int64_t i = 0; i < Q; i++) {
+                radius[i] = c->h_xout[i].radius;
+                if (idx) idx[i] = c->h_xout[i].idx;
+                if (d2) d2[i] = c->h_xout[i].d2;
+            }
+            return PCT_OK;
+        }
+        PCTCHK(pct_cloud_reserve_queries(c, Q));
+        HIPCHK(hipMemcpyAsync(c->d_pts64, pts, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
+        ring_batch_kernel<true><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), to_dev(p), nullptr, c->d_pts64, stop_d2, (uint32_t)c->index_base, c->d_idx, c->d_d2,
+                                                              c->d_radius, nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(radius, c->d_radius, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+        if (idx) HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
+        if (d2) HIPCHK(hipMemcpyAsync(d2, c->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
+        HIPCHK(hipStreamSynchronize(g_stream));
+        return PCT_OK;
+    }
     if (Q <= kExpressMaxQ && c->has_grid && c->count > 0) {   // express: one fused launch (a block per point), arguments and results in mapped memory
         std::memcpy(c->h_xin, pts, sizeof(double) * 3 * Q);
         // idx / d2 not wanted: the search may stop once everything unseen is beyond max_radius + search_margin
@@ -1371,6 +1445,14 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
     for (int i = 0; i < traj->nseg; i++)
         if (traj->orders[i] < 0 || traj->orders[i] > kMaxBezierOrder || 3 * (traj->orders[i] + 1) > traj->row_stride)
             return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
+    if (c->ring_ready) {          // rolling map: the fused planner batch with samples only
+        pct_replan_out o{};
+        o.sample_pos = pos; o.sample_radius = radius; o.sample_d2 = d2; o.sample_idx = idx;
+        PCTCHK(replan_direct(c, p, nullptr, 0, traj, t_start, stop_time, dt, (idx || d2) ? 1 : 0, 0, (int)cap, &o));
+        *nsamples = o.nsamples;
+        *first_hit = o.first_hit_sample;
+        return PCT_OK;
+    }
     const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
     if (ncoef + (size_t)traj->nseg <= 3 * (size_t)kExpressMaxQ - 64) {
         // express: the host enumerates the sample times (sim_planning_demo.cpp:729-771, the same sequential fp64 additions as
@@ -1470,6 +1552,30 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
 }
 
 // ---- hipGraph plan -----------------------------------------------------------------------
+static int plan_capture_nn(pct_plan *p)
+{
+    pct_cloud *c = p->c;
+    if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    PCTCHK(pct_cloud_reserve_queries(c, p->Q));
+    HIPCHK(hipStreamSynchronize(g_stream));
+    hipError_t e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    c->capturing = true;
+    (void)hipMemcpyAsync(p->d_q, p->h_q, sizeof(float) * 3 * p->Q, hipMemcpyHostToDevice, g_stream);
+    const int st = nn_dev(c, p->algo, p->d_q, p->Q, p->d_idx, p->d_d2, g_stream);
+    (void)hipMemcpyAsync(p->h_idx, p->d_idx, sizeof(uint32_t) * p->Q, hipMemcpyDeviceToHost, g_stream);
+    (void)hipMemcpyAsync(p->h_d2, p->d_d2, sizeof(double) * p->Q, hipMemcpyDeviceToHost, g_stream);
+    c->capturing = false;
+    e = hipStreamEndCapture(g_stream, &p->graph);
+    if (st != PCT_OK) return st;
+    if (e != hipSuccess || !p->graph) return fail(PCT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    p->generation = c->generation;
+    return PCT_OK;
+}
+
 int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out)
 {
     if (!c || !out || Q <= 0) return fail(PCT_ERR_INVALID, "bad plan arguments");
@@ -1478,6 +1584,7 @@ int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out)
     if (!p) return fail(PCT_ERR_ALLOC, "host allocation failed");
     p->c = c;
     p->Q = Q;
+    p->algo = algo;
     hipError_t e = hipHostMalloc((void **)&p->h_q, sizeof(float) * 3 * Q, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_idx, sizeof(uint32_t) * Q, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->h_d2, sizeof(double) * Q, hipHostMallocDefault);
@@ -1486,28 +1593,19 @@ int pct_plan_create_nn(pct_cloud *c, int algo, int64_t Q, pct_plan **out)
     if (!st) st = dev_alloc(&p->d_q, 3 * Q);
     if (!st) st = dev_alloc(&p->d_idx, Q);
     if (!st) st = dev_alloc(&p->d_d2, Q);
+    if (!st) st = plan_capture_nn(p);
     if (st) { pct_plan_destroy(p); return st; }
-    HIPCHK(hipStreamSynchronize(g_stream));
-    e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
-    c->capturing = true;
-    (void)hipMemcpyAsync(p->d_q, p->h_q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream);
-    st = nn_dev(c, algo, p->d_q, Q, p->d_idx, p->d_d2, g_stream);
-    (void)hipMemcpyAsync(p->h_idx, p->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream);
-    (void)hipMemcpyAsync(p->h_d2, p->d_d2, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream);
-    c->capturing = false;
-    e = hipStreamEndCapture(g_stream, &p->graph);
-    if (st != PCT_OK) { pct_plan_destroy(p); return st; }
-    if (e != hipSuccess || !p->graph) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
-    e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
-    if (e != hipSuccess) { pct_plan_destroy(p); return fail(PCT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
     *out = p;
     return PCT_OK;
 }
 
 int pct_plan_run(pct_plan *p, const float *q, uint32_t *idx, double *d2)
 {
-    if (!p || !q || !idx || !d2) return fail(PCT_ERR_INVALID, "bad plan_run arguments");
+    if (!p || p->kind != 0 || !q || !idx || !d2) return fail(PCT_ERR_INVALID, "bad plan_run arguments");
+    // The captured kernels hold the cloud's point count, its index description and its workspace pointers.  When any of them
+    // has changed since the capture (upload / append, grid build or drop, a larger batch elsewhere that reallocated the
+    // workspaces) the cloud's generation has moved on and the graph is captured again before it runs.
+    if (p->generation != p->c->generation) PCTCHK(plan_capture_nn(p));
     memcpy(p->h_q, q, sizeof(float) * 3 * p->Q);
     HIPCHK(hipGraphLaunch(p->exec, g_stream));
     HIPCHK(hipStreamSynchronize(g_stream));
@@ -1526,6 +1624,7 @@ int pct_plan_destroy(pct_plan *p)
     if (p->h_idx) (void)hipHostFree(p->h_idx);
     if (p->h_d2) (void)hipHostFree(p->h_d2);
     dev_free(p->d_q); dev_free(p->d_idx); dev_free(p->d_d2);
+    replan_ctx_free(p->rx);
     delete p;
     return PCT_OK;
 }

@@ -1,0 +1,428 @@
+// ring.hpp -- incremental cell index for the ROLLING obstacle map (config C5) and the fused replan batch.
+//
+// The planner's cloud callback replaces the obstacle index on every sensor frame
+// (safeRegionRrtStar::setInput, Planner/src/corridor_finder.cpp:93-99: a full FLANN rebuild) and then runs the
+// collision check (sim_planning_demo.cpp:159-178).  For a rolling window (pct_cloud_append_aos: the newest frame overwrites
+// the oldest ring slots) a rebuild per frame costs more than the queries it serves, so the window keeps an index that is
+// UPDATED in place:
+//
+//   * cells are world-anchored: cell(p) = floor(p / h) per axis in fp64 (exact enough that the h/256 slack of the search
+//     bound is never needed), folded into a power-of-two table by (c & (g - 1)) -- toroidal addressing, so the table follows
+//     the drone without ever being re-centred.  Two world cells that fold onto one bucket merely share it: every distance is
+//     computed from the stored coordinates, and the termination bound below only speaks about buckets NOT yet visited.
+//   * a bucket is a short queue of kRingK {x, y, z, ring slot} records with monotonic head/tail counters; where[slot] remembers
+//     the place a ring slot's record was filed.  Evicting a point = marking ITS record dead (no search) and letting the
+//     bucket's head move past dead records; a rolling window evicts in arrival order, so heads keep up with the evictions.
+//   * a bucket that is full sends the newcomer to one global overflow queue (same discipline).  Queries scan that queue
+//     exhaustively; it is empty unless the cloud has more than kRingK points in one cell (bulk duplicates, surfaces sampled
+//     far finer than the cell).
+//
+// Search = the same expanding-cube search as the cell-sorted index (kernels.hpp section 4), same fp64 arithmetic
+// ((dx*dx + dy*dy) + dz*dz, no FMA), winner by (d2, ring slot): lowest slot on exact ties.
+#pragma once
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace pct {
+
+constexpr uint32_t kRingK = 32;                 // records per bucket (power of two)
+constexpr int kRingCellClamp = 1000000000;      // |cell coordinate| limit (non-finite / absurd coordinates land on the limit)
+
+struct RingDesc {
+    double inv_h, h;
+    int gx, gy, gz;          // bucket table dimensions, powers of two
+    int lx, ly;              // log2(gx), log2(gy)
+    uint32_t ovf_mask;       // overflow queue capacity - 1 (power of two >= cloud capacity: the queue itself cannot overflow)
+};
+
+// device-resident state the append kernels maintain and the query kernels read: a captured hipGraph stays valid across appends
+struct RingState {
+    uint32_t ovf_head, ovf_tail;     // monotonic; live entries are [head, tail)
+    uint32_t count;                  // valid points in the ring
+    uint32_t pad;
+};
+
+__device__ __forceinline__ int ring_cell_coord(double v, double inv_h, bool &wild)
+{
+    const double c = floor(v * inv_h);
+    if (!(c > -(double)kRingCellClamp && c < (double)kRingCellClamp)) {     // also NaN
+        wild = true;
+        return c > 0.0 ? kRingCellClamp : -kRingCellClamp;
+    }
+    return (int)c;
+}
+
+__device__ __forceinline__ uint32_t ring_lin(const RingDesc &R, int cx, int cy, int cz)
+{
+    return ((uint32_t)(cz & (R.gz - 1)) << (R.lx + R.ly)) | ((uint32_t)(cy & (R.gy - 1)) << R.lx) | (uint32_t)(cx & (R.gx - 1));
+}
+
+__device__ __forceinline__ uint32_t ring_bucket_of(const RingDesc &R, float x, float y, float z)
+{
+    bool wild = false;
+    const int cx = ring_cell_coord((double)x, R.inv_h, wild), cy = ring_cell_coord((double)y, R.inv_h, wild),
+              cz = ring_cell_coord((double)z, R.inv_h, wild);
+    return ring_lin(R, cx, cy, cz);
+}
+
+// where[slot]: the place a ring slot's record was filed -- bit 31 set = position in the overflow queue, clear = sequence number
+// inside its bucket.  Eviction goes straight to the record (no search) and marks it dead; heads then advance past dead records.
+constexpr uint32_t kRingInOvf = 0x80000000u;
+constexpr uint32_t kRingDead = 0xFFFFFFFFu;      // a record's id word once its point has left the window
+
+// file one point under its bucket (or the overflow queue when the bucket is full); heads do not move while this runs
+__device__ __forceinline__ void ring_file(const RingDesc &R, float px, float py, float pz, uint32_t slot, uint2 *__restrict__ ht,
+                                          float4 *__restrict__ slots, float4 *__restrict__ ovf, uint32_t *__restrict__ where,
+                                          RingState *__restrict__ st)
+{
+    const uint32_t b = ring_bucket_of(R, px, py, pz);
+    const float4 rec = make_float4(px, py, pz, __uint_as_float(slot));
+    const uint32_t h = ht[b].x;
+    uint32_t t = __hip_atomic_load(&ht[b].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (t - h >= kRingK) break;                                 // full: overflow queue
+        const uint32_t seen = atomicCAS(&ht[b].y, t, t + 1u);
+        if (seen == t) {
+            slots[(size_t)b * kRingK + (t & (kRingK - 1))] = rec;
+            where[slot] = t & ~kRingInOvf;
+            return;
+        }
+        t = seen;
+    }
+    const uint32_t pos = atomicAdd(&st->ovf_tail, 1u);
+    ovf[pos & R.ovf_mask] = rec;
+    where[slot] = (pos & ~kRingInOvf) | kRingInOvf;
+}
+
+// Pass 1 of an append: one thread per ring slot about to be overwritten retires the point the slot holds -- its record is
+// marked dead where it was filed, then the owning FIFO's head moves past every dead record in front (several threads may try:
+// the compare-and-swap lets each step happen once).  No record is filed while this runs.
+__global__ __launch_bounds__(256) void ring_evict_kernel(RingDesc R, const float *__restrict__ x, const float *__restrict__ y,
+                                                         const float *__restrict__ z, uint32_t slot0, uint32_t n,
+                                                         uint2 *__restrict__ ht, float4 *__restrict__ slots, float4 *__restrict__ ovf,
+                                                         const uint32_t *__restrict__ where, RingState *__restrict__ st)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = slot0 + i;
+    const uint32_t w = where[slot];
+    if (w & kRingInOvf) {
+        uint32_t *idw = reinterpret_cast<uint32_t *>(&ovf[w & R.ovf_mask].w);
+        __hip_atomic_store(idw, kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t tail = st->ovf_tail;
+        uint32_t h = __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (h != tail) {
+            const uint32_t *hw = reinterpret_cast<const uint32_t *>(&ovf[h & R.ovf_mask].w);
+            if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
+            const uint32_t seen = atomicCAS(&st->ovf_head, h, h + 1u);
+            h = seen == h ? h + 1u : seen;
+        }
+        return;
+    }
+    const uint32_t b = ring_bucket_of(R, x[slot], y[slot], z[slot]);
+    float4 *base = slots + (size_t)b * kRingK;
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(&base[w & (kRingK - 1)].w), kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t tail = ht[b].y;
+    uint32_t h = __hip_atomic_load(&ht[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (h != tail) {
+        const uint32_t *hw = reinterpret_cast<const uint32_t *>(&base[h & (kRingK - 1)].w);
+        if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
+        const uint32_t seen = atomicCAS(&ht[b].x, h, h + 1u);
+        h = seen == h ? h + 1u : seen;
+    }
+}
+
+// Pass 2: store the new frame in the SoA arrays and file it.  `src` = the frame, array of structures (x,y,z at byte offsets
+// 0,4,8 of each stride-byte record) in device-visible memory.
+__global__ __launch_bounds__(256) void ring_insert_kernel(RingDesc R, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z,
+                                                          const unsigned char *__restrict__ src, uint32_t stride, uint32_t n,
+                                                          uint32_t slot0, uint2 *__restrict__ ht, float4 *__restrict__ slots,
+                                                          float4 *__restrict__ ovf, uint32_t *__restrict__ where, RingState *__restrict__ st)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = slot0 + i;
+    const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
+    const float px = p[0], py = p[1], pz = p[2];
+    x[slot] = px; y[slot] = py; z[slot] = pz;
+    ring_file(R, px, py, pz, slot, ht, slots, ovf, where, st);
+}
+
+// file the points already in the SoA arrays (slots [slot0, slot0 + n)) after the tables have been cleared: the index of a
+// freshly uploaded cloud, or a rebuild with another cell size
+__global__ __launch_bounds__(256) void ring_refile_kernel(RingDesc R, const float *__restrict__ x, const float *__restrict__ y,
+                                                          const float *__restrict__ z, uint32_t slot0, uint32_t n,
+                                                          uint2 *__restrict__ ht, float4 *__restrict__ slots, float4 *__restrict__ ovf,
+                                                          uint32_t *__restrict__ where, RingState *__restrict__ st)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = slot0 + i;
+    ring_file(R, x[slot], y[slot], z[slot], slot, ht, slots, ovf, where, st);
+}
+
+__global__ void ring_set_count_kernel(RingState *st, uint32_t count) { st->count = count; }
+
+// ---- block-wide search ---------------------------------------------------------------------------------------------------
+// Everything a query kernel needs to search one cloud: either index kind behind one handle.
+struct RingView {
+    RingDesc R;
+    const uint2 *ht;
+    const float4 *slots;
+    const float4 *ovf;
+    const RingState *st;
+};
+
+// all records of one bucket against the query, exact fp64, four loads in flight
+__device__ __forceinline__ void ring_scan_bucket(const RingView &V, uint32_t b, double qx, double qy, double qz, double &bd, uint32_t &bi)
+{
+    const uint2 m = V.ht[b];
+    const uint32_t n = m.y - m.x;
+    const float4 *base = V.slots + (size_t)b * kRingK;
+    for (uint32_t j = 0; j < n; j += 4) {
+        float4 P[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) P[k] = base[(m.x + min(j + (uint32_t)k, n - 1)) & (kRingK - 1)];     // tail repeats the last record
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double d2 = dist2((double)P[k].x, (double)P[k].y, (double)P[k].z, qx, qy, qz);
+            const uint32_t id = __float_as_uint(P[k].w);
+            if (id != kRingDead && better(d2, id, bd, bi)) { bd = d2; bi = id; }
+        }
+    }
+}
+
+// Nearest point of the fp32-narrowed (px, py, pz) over a ring-indexed cloud; one 256-thread block, ONE THREAD PER BUCKET of the
+// cube / shell being examined (a bucket holds ~6 records: a thread reads its head/tail pair, then its records, four at a time),
+// block-wide fold after every shell.  stop_d2 as in block_nn_search (kernels.hpp): when only the radius is wanted the search may
+// stop once everything unseen is beyond max_radius + search_margin.
+//
+// Exactness: after the cube of world cells [c - r, c + r]^3 has been visited (every bucket a cube cell folds onto), a point not
+// yet seen lies in an unvisited bucket, so its world cell differs from every visited one along some axis that is still "open"
+// (2r + 1 < table size on that axis), and along that axis it is beyond the cube's face: farther than the face distance.  The
+// search stops only when best <= (min open face distance - h/256)^2, or when no axis is open (every bucket has been visited).
+__device__ __forceinline__ void ring_block_nn_search(const RingView &V, double px, double py, double pz, double stop_d2,
+                                                     double *s_d, uint32_t *s_i, double &bd, uint32_t &bi)
+{
+    const RingDesc &R = V.R;
+    const float qxf = (float)px, qyf = (float)py, qzf = (float)pz;                    // searchPoint.x = search_Pt(0), :125-128
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
+    {   // overflow queue: exhaustive
+        const uint32_t oh = V.st->ovf_head, on = V.st->ovf_tail - oh;
+        for (uint32_t k = threadIdx.x; k < on; k += 256) {
+            const float4 P = V.ovf[(oh + k) & R.ovf_mask];
+            const double d2 = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
+            const uint32_t id = __float_as_uint(P.w);
+            if (id != kRingDead && better(d2, id, bd, bi)) { bd = d2; bi = id; }
+        }
+    }
+    bool wild = false;
+    const int cx = ring_cell_coord(qx, R.inv_h, wild), cy = ring_cell_coord(qy, R.inv_h, wild), cz = ring_cell_coord(qz, R.inv_h, wild);
+    for (int r = 1;; r++) {
+        // an axis is open while the cube does not yet wrap around the table on it (a query with an absurd coordinate has none)
+        const bool ox = !wild && 2 * r + 1 < R.gx, oy = !wild && 2 * r + 1 < R.gy, oz = !wild && 2 * r + 1 < R.gz;
+        const bool was_x = !wild && 2 * r - 1 < R.gx, was_y = !wild && 2 * r - 1 < R.gy, was_z = !wild && 2 * r - 1 < R.gz;
+        // positions per axis: the cube's 2r+1 world cells while open, the whole table once closed
+        const int nx = ox ? 2 * r + 1 : R.gx, ny = oy ? 2 * r + 1 : R.gy, nz = oz ? 2 * r + 1 : R.gz;
+        const int x0 = ox ? cx - r : 0, y0 = oy ? cy - r : 0, z0 = oz ? cz - r : 0;
+        if (r == 1 || (!ox && was_x) || (!oy && was_y) || (!oz && was_z)) {
+            // first cube, or an axis has just closed (or the query is wild): visit the whole box; buckets seen before are
+            // merely seen again (a repeated (d2, slot) never changes the winner)
+            const int total = nx * ny * nz;
+            for (int k = (int)threadIdx.x; k < total; k += 256) {
+                const int jx = k % nx, jy = (k / nx) % ny, jz = k / (nx * ny);
+                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi);
+            }
+        } else {
+            // shell r: two z-faces, then two y-faces without the z-face rows, then two x-faces without either
+            const int nyi = oy ? ny - 2 : ny, nzi = oz ? nz - 2 : nz;
+            const int A = oz ? 2 * nx * ny : 0, B = oy ? 2 * nx * nzi : 0, Cc = ox ? 2 * nyi * nzi : 0;
+            for (int k = (int)threadIdx.x; k < A + B + Cc; k += 256) {
+                int jx, jy, jz;
+                if (k < A) {
+                    const int f = k / (nx * ny), rem = k % (nx * ny);
+                    jz = f ? nz - 1 : 0; jy = rem / nx; jx = rem % nx;
+                } else if (k < A + B) {
+                    const int k2 = k - A, f = k2 / (nx * nzi), rem = k2 % (nx * nzi);
+                    jy = f ? ny - 1 : 0; jz = (oz ? 1 : 0) + rem / nx; jx = rem % nx;
+                } else {
+                    const int k3 = k - A - B, f = k3 / (nyi * nzi), rem = k3 % (nyi * nzi);
+                    jx = f ? nx - 1 : 0; jz = (oz ? 1 : 0) + rem / nyi; jy = (oy ? 1 : 0) + rem % nyi;
+                }
+                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi);
+            }
+        }
+        block_argmin256(bd, bi, s_d, s_i);
+        double bound = __builtin_huge_val();
+        if (ox) bound = fmin(bound, fmin(qx - (double)(cx - r) * R.h, (double)(cx + r + 1) * R.h - qx));
+        if (oy) bound = fmin(bound, fmin(qy - (double)(cy - r) * R.h, (double)(cy + r + 1) * R.h - qy));
+        if (oz) bound = fmin(bound, fmin(qz - (double)(cz - r) * R.h, (double)(cz + r + 1) * R.h - qz));
+        if (bound == __builtin_huge_val()) break;                   // every bucket has been visited
+        bound -= R.h * (1.0 / 256.0);
+        if (bound > 0.0 && (bd <= bound * bound || bound * bound >= stop_d2)) break;
+    }
+}
+
+// ---- the fused planner batch ----------------------------------------------------------------------------------------------
+// One launch answers everything a replan tick asks of the obstacle cloud (sim_planning_demo.cpp:159-178 -> :729-781, and
+// SafeRegionEvaluate's re-check loop corridor_finder.cpp:829-835): a 256-thread block per planner point, three kinds of blocks:
+//   [0, n_nodes)                      corridor nodes: radiusSearch of the node centre (checkRadius, :656-659)
+//   [n_nodes, +n_samples)             Bezier samples: getPosFromBezier (:715-727) of the host-enumerated (segment, t), then
+//                                     radiusSearch; collision <=> radius < 0 (checkTrajPtCol, corridor_finder.cpp:412-416)
+//   [.., +n_ctrl)                     control points: the raw control point j of segment i scaled by T_i (the point the
+//                                     optimizer's cone constraint keeps inside sphere i, traj_optimizer.cpp:624-648, in world
+//                                     units as traj_optimizer.cpp:739-751 stores it), same threshold test -- SURVEY 3.3's
+//                                     build extension for config C5
+// Blocks beyond the counts in the argument block exit at once, so one captured grid serves every tick.
+struct ReplanHeader {
+    InflateParams P;
+    int32_t n_nodes, n_samples, n_ctrl, nseg;
+    int32_t row_stride, want_nn, first_seg;
+    uint32_t seq;            // echoed into the summary once every result is in the caller's buffer (the host may poll for it)
+    // offsets (in doubles / in uint32s) of the variable parts inside the argument block
+    uint32_t off_nodes, off_coef, off_segtime, off_sample_t;       // in doubles from the start of the f64 area
+    uint32_t off_orders, off_sample_seg, off_ctrl_seg, off_ctrl_j; // in uint32s from the start of the u32 area
+};
+
+struct ReplanSummary { long long first_hit_sample, first_hit_ctrl; int32_t n_nodes, n_samples, n_ctrl; uint32_t seq; };
+
+template <bool RING>
+__global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc G0, const float4 *__restrict__ pts0,
+                                                           const uint32_t *__restrict__ cs0, CoarseLevels C, int static_count,
+                                                           const ReplanHeader *__restrict__ hdr, const double *__restrict__ f64a,
+                                                           const uint32_t *__restrict__ u32a, uint32_t index_base,
+                                                           ExpressOut *__restrict__ out, double *__restrict__ pos_out)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    __shared__ double s_term[3 * (kMaxBezierOrder + 1)];
+    __shared__ double s_pos[3];
+    const ReplanHeader H = *hdr;
+    const int slot = (int)blockIdx.x;
+    if (slot >= H.n_nodes + H.n_samples + H.n_ctrl) return;
+    const InflateParams P = H.P;
+    double px, py, pz;
+    if (slot < H.n_nodes) {
+        const double *nd = f64a + H.off_nodes + 3 * (size_t)slot;
+        px = nd[0]; py = nd[1]; pz = nd[2];
+    } else if (slot < H.n_nodes + H.n_samples) {
+        const int s = slot - H.n_nodes;
+        const int seg = (int)u32a[H.off_sample_seg + s];
+        const int order = (int)u32a[H.off_orders + seg], m = order + 1;
+        const double T = f64a[H.off_segtime + seg];
+        const double u = f64a[H.off_sample_t + s] / T;
+        if ((int)threadIdx.x < 3 * m) {
+            const int d = (int)threadIdx.x / m, j = (int)threadIdx.x % m;
+            double b = 1.0;                                            // bezier_base.cpp:33-48 binomials as exact doubles
+            for (int i = 1; i <= j; i++) b = floor(b * (double)(order - i + 1) / (double)i + 0.5);
+            s_term[d * m + j] = b * f64a[H.off_coef + (size_t)seg * H.row_stride + d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double acc = 0.0;
+            for (int j = 0; j < m; j++) acc += s_term[threadIdx.x * m + j];
+            s_pos[threadIdx.x] = acc * T;
+        }
+        __syncthreads();
+        px = s_pos[0]; py = s_pos[1]; pz = s_pos[2];
+    } else {
+        const int k = slot - H.n_nodes - H.n_samples;
+        const int seg = (int)u32a[H.off_ctrl_seg + k], j = (int)u32a[H.off_ctrl_j + k];
+        const int m = (int)u32a[H.off_orders + seg] + 1;
+        const double T = f64a[H.off_segtime + seg];
+        const double *c = f64a + H.off_coef + (size_t)seg * H.row_stride;
+        px = c[j] * T; py = c[m + j] * T; pz = c[2 * m + j] * T;
+    }
+    if (threadIdx.x < 3 && slot >= H.n_nodes) pos_out[3 * (size_t)(slot - H.n_nodes) + threadIdx.x] = threadIdx.x == 0 ? px : threadIdx.x == 1 ? py : pz;
+    const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
+    const bool empty = RING ? V.st->count == 0 : static_count == 0;
+    if (empty || sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {          // corridor_finder.cpp:115-116
+        if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); out[slot].count = 0; }
+        return;
+    }
+    const double reach = P.max_radius + P.search_margin;
+    const double stop_d2 = H.want_nn ? __builtin_huge_val() : reach * reach;
+    double bd;
+    uint32_t bi;
+    if (RING) ring_block_nn_search(V, px, py, pz, stop_d2, s_d, s_i, bd, bi);
+    else block_nn_search(G0, pts0, cs0, C, px, py, pz, stop_d2, s_d, s_i, bd, bi);
+    if (threadIdx.x == 0) {
+        const double rr = sqrt(bd) - P.search_margin;
+        out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        out[slot].d2 = bd;
+        out[slot].count = 0;
+    }
+}
+
+// first colliding sample / control point (radius < 0), and the results handed to the caller's (host-visible) buffer in one sweep
+__global__ __launch_bounds__(256) void replan_finish_kernel(const ReplanHeader *__restrict__ hdr, const ExpressOut *__restrict__ res,
+                                                            ExpressOut *__restrict__ res_host, ReplanSummary *__restrict__ sum)
+{
+    __shared__ int s_fs, s_fc;
+    if (threadIdx.x == 0) { s_fs = 0x7FFFFFFF; s_fc = 0x7FFFFFFF; }
+    __syncthreads();
+    const int nn = hdr->n_nodes, ns = hdr->n_samples, nc = hdr->n_ctrl;
+    int fs = 0x7FFFFFFF, fc = 0x7FFFFFFF;
+    for (int i = (int)threadIdx.x; i < nn + ns + nc; i += 256) {
+        const ExpressOut e = res[i];
+        if (res_host) res_host[i] = e;
+        if (e.radius < 0.0) {
+            if (i >= nn && i < nn + ns) fs = min(fs, i - nn);
+            else if (i >= nn + ns) fc = min(fc, i - nn - ns);
+        }
+    }
+    atomicMin(&s_fs, fs);
+    atomicMin(&s_fc, fc);
+    __threadfence_system();                     // this thread's records are in the caller's buffer before the block goes on
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sum->first_hit_sample = s_fs == 0x7FFFFFFF ? -1ll : (long long)s_fs;
+        sum->first_hit_ctrl = s_fc == 0x7FFFFFFF ? -1ll : (long long)s_fc;
+        sum->n_nodes = nn; sum->n_samples = ns; sum->n_ctrl = nc;
+        __hip_atomic_store(&sum->seq, hdr->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // last: the host polls this word
+    }
+}
+
+// plain NN / inflation of a device batch over a ring-indexed cloud: a block per query (the rolling map serves the planner's
+// small batches; large throughput batches belong to the cell-sorted index)
+template <bool INFLATE>
+__global__ __launch_bounds__(256) void ring_batch_kernel(RingView V, InflateParams P, const float *__restrict__ qf, const double *__restrict__ q64,
+                                                         double stop_d2, uint32_t index_base, uint32_t *__restrict__ out_idx,
+                                                         double *__restrict__ out_d2, double *__restrict__ out_radius,
+                                                         ExpressOut *__restrict__ out_rec)
+{
+    __shared__ double s_d[4];
+    __shared__ uint32_t s_i[4];
+    const size_t slot = blockIdx.x;
+    double px, py, pz;
+    if (q64) { px = q64[3 * slot]; py = q64[3 * slot + 1]; pz = q64[3 * slot + 2]; }
+    else { px = (double)qf[3 * slot]; py = (double)qf[3 * slot + 1]; pz = (double)qf[3 * slot + 2]; }
+    double bd = __builtin_huge_val(), radius = 0.0;
+    uint32_t bi = kNoIndex;
+    bool skip = V.st->count == 0;
+    if (INFLATE) {
+        const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
+        skip = skip || sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius;
+        radius = P.max_radius - P.search_margin;
+    }
+    if (!skip) {
+        ring_block_nn_search(V, px, py, pz, stop_d2, s_d, s_i, bd, bi);
+        if (INFLATE) {
+            const double rr = sqrt(bd) - P.search_margin;
+            radius = rr < P.max_radius ? rr : P.max_radius;
+        }
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t gi = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        if (out_idx) out_idx[slot] = gi;
+        if (out_d2) out_d2[slot] = bd;
+        if (out_radius) out_radius[slot] = radius;
+        if (out_rec) { out_rec[slot].idx = gi; out_rec[slot].d2 = bd; out_rec[slot].radius = radius; out_rec[slot].count = 0; }
+    }
+}
+
+}  // namespace pct

@@ -29,6 +29,13 @@ class InflateParams(C.Structure):
                 ("max_radius", C.c_double)]
 
 
+class ReplanOut(C.Structure):
+    _fields_ = [("node_radius", C.c_void_p), ("node_idx", C.c_void_p), ("node_d2", C.c_void_p),
+                ("sample_pos", C.c_void_p), ("sample_radius", C.c_void_p), ("sample_d2", C.c_void_p), ("sample_idx", C.c_void_p),
+                ("ctrl_pos", C.c_void_p), ("ctrl_radius", C.c_void_p), ("ctrl_d2", C.c_void_p), ("ctrl_idx", C.c_void_p),
+                ("nsamples", C.c_int64), ("first_hit_sample", C.c_int64), ("nctrl", C.c_int64), ("first_hit_ctrl", C.c_int64)]
+
+
 class BezierTraj(C.Structure):
     _fields_ = [("polycoef", C.POINTER(C.c_double)), ("row_stride", C.c_int64), ("seg_time", C.POINTER(C.c_double)),
                 ("orders", C.POINTER(C.c_int32)), ("nseg", C.c_int32)]
@@ -93,6 +100,15 @@ def lib():
         L.pct_plan_create_nn.argtypes = [vp, i32, i64, C.POINTER(vp)]
         L.pct_plan_run.argtypes = [vp, f32p, u32p, f64p]
         L.pct_plan_destroy.argtypes = [vp]
+        L.pct_cloud_ring_index.argtypes = [vp, C.c_float, vp]
+        L.pct_cloud_ring_drop.argtypes = [vp]
+        L.pct_cloud_has_ring_index.argtypes = [vp]
+        L.pct_cloud_ring_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(i64)]
+        L.pct_ctrl_points_check.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.POINTER(i64), C.POINTER(i64),
+                                            i64, f64p, f64p, f64p, u32p]
+        L.pct_plan_create_replan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.pct_plan_replan_run.argtypes = [vp, C.POINTER(InflateParams), f64p, i64, C.POINTER(BezierTraj), C.c_double, C.c_double, C.c_double,
+                                          C.c_int, C.POINTER(ReplanOut)]
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
@@ -216,6 +232,25 @@ class Cloud:
         _chk(lib().pct_cloud_grid_info(self._h, dims, C.byref(h), org, C.byref(nc)))
         return dict(dims=tuple(dims), cell_size=h.value, origin=tuple(org), ncells=nc.value)
 
+    def ring_index(self, cell_size: float = 0.0, extent=None):
+        """rolling-map index (pct_cloud_ring_index): appends update it in place instead of dropping an index"""
+        ext = None if extent is None else np.ascontiguousarray(extent, np.float32).reshape(3)
+        _chk(lib().pct_cloud_ring_index(self._h, float(cell_size), None if ext is None else ext.ctypes.data))
+
+    def ring_drop(self):
+        _chk(lib().pct_cloud_ring_drop(self._h))
+
+    @property
+    def has_ring_index(self) -> bool:
+        return bool(lib().pct_cloud_has_ring_index(self._h))
+
+    def ring_info(self):
+        dims = (C.c_int32 * 3)()
+        h = C.c_double()
+        ov = C.c_int64()
+        _chk(lib().pct_cloud_ring_info(self._h, dims, C.byref(h), C.byref(ov)))
+        return dict(dims=tuple(dims), cell_size=h.value, overflow_entries=ov.value)
+
     def reserve_queries(self, Q: int):
         _chk(lib().pct_cloud_reserve_queries(self._h, int(Q)))
 
@@ -281,6 +316,19 @@ class Cloud:
         n = min(ns.value, cap)
         return dict(first_hit=fh.value, n=ns.value, pos=pos[:n], radius=rad[:n], d2=d2[:n], idx=idx[:n])
 
+    def ctrl_points_check(self, params: InflateParams, polycoef, seg_time, orders, t_start=0.0, cap=1024):
+        """pct_ctrl_points_check: the collision threshold test on the raw control points (world units)"""
+        traj, keep = _traj(polycoef, seg_time, orders)
+        pos = np.zeros((cap, 3), np.float64)
+        rad = np.zeros(cap, np.float64)
+        d2 = np.zeros(cap, np.float64)
+        idx = np.zeros(cap, np.uint32)
+        fh, nc = C.c_int64(), C.c_int64()
+        _chk(lib().pct_ctrl_points_check(self._h, C.byref(traj), C.byref(params), float(t_start), C.byref(fh), C.byref(nc), cap,
+                                         _ptr(pos), _ptr(rad), _ptr(d2), _ptr(idx)))
+        n = min(nc.value, cap)
+        return dict(first_hit=fh.value, n=nc.value, pos=pos[:n], radius=rad[:n], d2=d2[:n], idx=idx[:n])
+
     # device-buffer variants: raw pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle
     def nn_device(self, q_ptr: int, Q: int, idx_ptr: int, d2_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
         _chk(lib().pct_nn_batch_dev(self._h, algo, q_ptr, int(Q), idx_ptr, d2_ptr, stream))
@@ -316,6 +364,56 @@ class Cloud:
         a, b = C.c_uint64(), C.c_uint64()
         _chk(lib().pct_last_work(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+
+def _traj(polycoef, seg_time, orders):
+    coef = np.ascontiguousarray(polycoef, np.float64)
+    st = np.ascontiguousarray(seg_time, np.float64)
+    od = np.ascontiguousarray(orders, np.int32)
+    t = BezierTraj(coef.ctypes.data_as(C.POINTER(C.c_double)), coef.shape[1], st.ctypes.data_as(C.POINTER(C.c_double)),
+                   od.ctypes.data_as(C.POINTER(C.c_int32)), len(st))
+    return t, (coef, st, od)
+
+
+class ReplanPlan:
+    """hipGraph-captured query side of one replan tick (pct_plan_create_replan): corridor-node inflation + sampled Bezier
+    check + control-point check in one launch."""
+
+    def __init__(self, cloud: Cloud, max_nodes: int, max_samples: int, max_segments: int):
+        self._h = C.c_void_p()
+        self._cloud = cloud
+        self.max_nodes, self.max_samples, self.max_segments = int(max_nodes), int(max_samples), int(max_segments)
+        _chk(lib().pct_plan_create_replan(cloud.handle, self.max_nodes, self.max_samples, self.max_segments, C.byref(self._h)))
+        nc = 13 * self.max_segments
+        self._b = dict(node_radius=np.zeros(self.max_nodes), node_idx=np.zeros(self.max_nodes, np.uint32), node_d2=np.zeros(self.max_nodes),
+                       sample_pos=np.zeros((self.max_samples, 3)), sample_radius=np.zeros(self.max_samples), sample_d2=np.zeros(self.max_samples),
+                       sample_idx=np.zeros(self.max_samples, np.uint32), ctrl_pos=np.zeros((nc, 3)), ctrl_radius=np.zeros(nc), ctrl_d2=np.zeros(nc),
+                       ctrl_idx=np.zeros(nc, np.uint32))
+        self._o = ReplanOut()
+        for k, v in self._b.items():
+            setattr(self._o, k, v.ctypes.data)
+
+    def run(self, params: InflateParams, nodes, polycoef=None, seg_time=None, orders=None, t_start=0.0, stop_time=2.0, dt=0.02, want_nn=True,
+            copy=True):
+        nd = np.ascontiguousarray(nodes, np.float64).reshape(-1, 3)
+        traj, keep = (None, None) if polycoef is None else _traj(polycoef, seg_time, orders)
+        _chk(lib().pct_plan_replan_run(self._h, C.byref(params), _ptr(nd), len(nd), None if traj is None else C.byref(traj), float(t_start),
+                                       float(stop_time), float(dt), int(bool(want_nn)), C.byref(self._o)))
+        o, b = self._o, self._b
+        ns, nc = min(o.nsamples, self.max_samples), o.nctrl
+        cp = (lambda a: a.copy()) if copy else (lambda a: a)
+        return dict(node_radius=cp(b["node_radius"][:len(nd)]), node_idx=cp(b["node_idx"][:len(nd)]), node_d2=cp(b["node_d2"][:len(nd)]),
+                    nsamples=o.nsamples, first_hit_sample=o.first_hit_sample, sample_pos=cp(b["sample_pos"][:ns]),
+                    sample_radius=cp(b["sample_radius"][:ns]), sample_d2=cp(b["sample_d2"][:ns]), sample_idx=cp(b["sample_idx"][:ns]),
+                    nctrl=nc, first_hit_ctrl=o.first_hit_ctrl, ctrl_pos=cp(b["ctrl_pos"][:nc]), ctrl_radius=cp(b["ctrl_radius"][:nc]),
+                    ctrl_d2=cp(b["ctrl_d2"][:nc]), ctrl_idx=cp(b["ctrl_idx"][:nc]))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and _lib is not None:
+            _lib.pct_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
 
 
 class NNPlan:

@@ -73,3 +73,43 @@ def timed_scenario(finder, cloud1, expand=1500, refine=400):
     out["status"] = finder.status()
     out["path_len"] = len(finder.getPath()[0])
     return out
+
+
+# ---- config C5: rolling window fed one sensor frame per tick ------------------------------------------
+C5_WINDOW, C5_FRAME = 5_000_000, 50_000
+C5_NODES, C5_SEGMENTS, C5_ORDER = 64, 3, 6
+C5_PARAMS = dict(sample_range=30.0, search_margin=0.25, max_radius=1.5)
+
+
+def c5_frame(k, frame=C5_FRAME, tunnel=0.0, step=0.1):
+    """sensor frame k: `frame` points uniform in a 60 m cube around a drone moving +`step` m per frame along x (seed 8),
+    flattened to a 6 m slab above the ground (|z| * 0.2).  tunnel > 0 (test variant): points closer than `tunnel` to the
+    flight axis (y = 0, z = 2.5) are moved sideways by 2 * tunnel, so the corridor ahead of the drone is free space and the
+    inflation radii are not all negative."""
+    p = synth.uniform_points(8, frame, -30.0, 30.0, offset=k * frame)
+    p[:, 0] += np.float32(step * k)
+    p[:, 2] = np.abs(p[:, 2]) * np.float32(0.2)
+    if tunnel > 0:
+        near = np.hypot(p[:, 1], p[:, 2] - np.float32(2.5)) < tunnel
+        p[near, 1] += np.where(p[near, 1] >= 0, np.float32(2 * tunnel), np.float32(-2 * tunnel))
+    return p
+
+
+def c5_tick_queries(k):
+    """what tick k asks of the cloud: the drone's pose, 64 corridor-node centres ahead of it (seed 9) and the committed
+    trajectory -- 3 segments of order 6, 1 s each, control points jittered by +-0.3 m (seed 9) around a straight 12 m run;
+    returns (start, nodes f64 [64,3], polycoef f64 [3,21] (control points / T as the optimizer stores them), seg_time, orders)"""
+    x0 = 0.1 * k
+    nodes = (synth.uniform_points(9, C5_NODES, -1.0, 1.0, offset=k * C5_NODES).astype(np.float64) * [8.0, 3.0, 1.0] + [x0 + 6.0, 0.0, 2.5])
+    m = C5_ORDER + 1
+    seg_time = np.ones(C5_SEGMENTS)
+    orders = np.full(C5_SEGMENTS, C5_ORDER, np.int32)
+    coef = np.zeros((C5_SEGMENTS, 3 * m))
+    ctrl = synth.uniform_points(9, C5_SEGMENTS * m, -0.3, 0.3, offset=1_000_000 + k * C5_SEGMENTS * m).astype(np.float64)
+    for sgm in range(C5_SEGMENTS):
+        for d in range(3):
+            for j in range(m):
+                w = (sgm + j / float(C5_ORDER)) / C5_SEGMENTS
+                base = [x0 + 12.0 * w, 0.0, 2.5][d]
+                coef[sgm, d * m + j] = (base + (ctrl[sgm * m + j, d] if 0 < j < C5_ORDER else 0.0)) / seg_time[sgm]
+    return (x0, 0.0, 2.5), nodes, coef, seg_time, orders

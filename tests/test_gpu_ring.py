@@ -1,0 +1,269 @@
+"""GPU tests of the rolling-map index (pct_cloud_ring_index) and the captured replan batch (pct_plan_create_replan), config C5.
+
+Oracle: the exhaustive fp64 scan of oracle/kdtree_port.c (okd_brute_nearestf: kdtree.c:379-382 arithmetic, lowest index on
+ties) over a host mirror of the ring, with the planner arithmetic of oracle/corridor_port.c around it (oracle.replan_tick).
+Bars: indices and squared distances bit-exact, radii bit-exact, sample enumeration / first hits exact, Bezier sample positions
+1e-12 relative (device pow vs libm pow; a sample whose fp32-narrowed position differs from the oracle's is reported and its
+NN compared against the oracle's answer for the DEVICE position instead).
+Planner arithmetic itself (inflation formula, Bezier sampling, control-point rule) is parity-unpinned."""
+import numpy as np
+import pytest
+
+from pointcloudtraj_amd import scenarios as S, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def E():
+    from pointcloudtraj_amd import engine
+    engine.init(0)
+    return engine
+
+
+class Mirror:
+    """host copy of a ring cloud: same slot discipline as pct_cloud_append_aos"""
+
+    def __init__(self, cap):
+        self.cap, self.count, self.nxt = cap, 0, 0
+        self.xyz = np.zeros((cap, 3), np.float32)
+
+    def append(self, f):
+        idx = (self.nxt + np.arange(len(f))) % self.cap
+        self.xyz[idx] = f
+        self.nxt = (self.nxt + len(f)) % self.cap
+        self.count = min(self.cap, self.count + len(f))
+
+    def live(self):
+        return self.xyz[:self.count]
+
+
+def check_nn(E, c, m, q, oracle, tag):
+    bi, bd = oracle.brute_nearest_mt(m.live(), q)
+    i1, d1 = c.nn(q)                                  # ALGO_AUTO -> the ring index
+    assert np.array_equal(d1, bd), f"{tag}: d2"
+    assert np.array_equal(i1.astype(np.int64), bi.astype(np.int64)), f"{tag}: idx"
+    i2, d2 = c.nn(q, E.ALGO_STREAM)                   # brute force over the SoA arrays the appends maintain
+    assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64)), f"{tag}: stream"
+
+
+def test_ring_index_irregular_appends(E, oracle):
+    """appends of irregular sizes (partial evictions of a frame, wrap-around inside one append), first fill included"""
+    cap = 200_000
+    c, m = E.Cloud(cap), Mirror(cap)
+    c.ring_index()
+    assert not c.has_ring_index                       # sized at the first data
+    sizes = [30_000, 7_001, 50_000, 64_000, 49_000, 13, 90_000, 33_333, 1, 120_000, 200_000, 25_000]
+    off = 0
+    for k, n in enumerate(sizes):
+        f = synth.uniform_points(31, n, 0.0, 40.0, offset=off)
+        f[:, 0] += np.float32(0.5 * k)
+        off += n
+        c.append(f)
+        m.append(f)
+        assert len(c) == m.count and c.has_ring_index
+        q = (synth.uniform_points(32 + k, 300, -2.0, 42.0) + np.float32([0.5 * k, 0, 0])).astype(np.float32)
+        check_nn(E, c, m, q, oracle, f"append {k}")
+    info = c.ring_info()
+    assert info["overflow_entries"] == 0
+    # big device batch (block per query) and inflation through the same index
+    q = synth.uniform_points(40, 5000, 0.0, 46.0)
+    check_nn(E, c, m, q, oracle, "batch 5000")
+    prm = E.inflate_params((20.0, 20.0, 20.0), 18.0, 0.25, 1.5)
+    pts = q[:1500].astype(np.float64) + 1e-4
+    rad, idx, d2 = c.inflate(prm, pts)
+    orad, oidx, od2 = oracle.inflate_brute(m.live(), (20.0, 20.0, 20.0), 18.0, 0.25, 1.5, pts)
+    assert np.array_equal(rad, orad) and np.array_equal(d2, od2)
+    assert np.array_equal(idx.astype(np.int64), np.where(oidx < 0, E.NO_INDEX, oidx).astype(np.int64))
+    rad2, idx2, d22 = c.inflate(prm, pts[:200])      # express size (mapped memory)
+    assert np.array_equal(rad2, orad[:200]) and np.array_equal(d22, od2[:200])
+    c.close()
+
+
+def test_ring_index_duplicates_and_overflow(E, oracle):
+    """more than 32 points in one cell (bulk duplicates + a tight cluster): the overflow queue holds them, evictions of queued
+    points work, ties go to the lowest ring slot"""
+    cap = 60_000
+    c, m = E.Cloud(cap), Mirror(cap)
+    c.ring_index(0.5, (20.0, 20.0, 20.0))
+    assert c.has_ring_index
+    base = synth.uniform_points(51, 20_000, 0.0, 20.0)
+    for k in range(7):
+        f = base.copy() if k % 2 == 0 else synth.uniform_points(52 + k, 20_000, 0.0, 20.0)
+        f[:3000] = np.float32([5.0, 5.0, 5.0])                                          # 3000 exact duplicates per frame
+        f[3000:6000] = (np.float32([7.0, 7.0, 7.0]) + synth.uniform_points(60 + k, 3000, 0.0, 0.01)).astype(np.float32)
+        c.append(f)
+        m.append(f)
+        q = np.concatenate([synth.uniform_points(70 + k, 200, 0.0, 20.0), np.float32([[5, 5, 5], [5.01, 5, 5], [7.004, 7.004, 7.004]]),
+                            base[:50]])
+        check_nn(E, c, m, q, oracle, f"frame {k}")
+        assert c.ring_info()["overflow_entries"] > 0
+    c.close()
+
+
+def test_ring_index_window_leaves_the_table(E, oracle):
+    """the window travels far beyond the table (several world cells fold onto one bucket), and queries far outside the window"""
+    cap = 100_000
+    c, m = E.Cloud(cap), Mirror(cap)
+    c.ring_index()
+    for k in range(14):
+        f = (synth.uniform_points(81, 20_000, 0.0, 10.0, offset=k * 20_000) + np.float32([17.0 * k, -3.0 * k, 0.5 * k])).astype(np.float32)
+        c.append(f)
+        m.append(f)
+        q = np.concatenate([(synth.uniform_points(82 + k, 150, -1.0, 11.0) + np.float32([17.0 * k, -3.0 * k, 0.5 * k])).astype(np.float32),
+                            synth.uniform_points(83 + k, 30, -300.0, 300.0)])
+        check_nn(E, c, m, q, oracle, f"frame {k}")
+    c.close()
+
+
+def compare_tick(E, got, ref, nodes_n, want_nn, tag):
+    assert got["nsamples"] == ref["nsamples"] and got["nctrl"] == ref["nctrl"], tag
+    assert np.array_equal(got["node_radius"], ref["node_radius"]), f"{tag}: node radii"
+    assert np.array_equal(got["ctrl_pos"], ref["ctrl_pos"]), f"{tag}: control points"
+    assert np.array_equal(got["ctrl_radius"], ref["ctrl_radius"]), f"{tag}: control-point radii"
+    assert got["first_hit_ctrl"] == ref["first_hit_ctrl"], tag
+    np.testing.assert_allclose(got["sample_pos"], ref["sample_pos"], rtol=1e-12, atol=1e-12)
+    same = np.all(got["sample_pos"].astype(np.float32) == ref["sample_pos"].astype(np.float32), axis=1)
+    assert np.array_equal(got["sample_radius"][same], ref["sample_radius"][same]), f"{tag}: sample radii"
+    if want_nn:
+        noidx = lambda a: np.where(a < 0, E.NO_INDEX, a).astype(np.int64)
+        assert np.array_equal(got["node_idx"].astype(np.int64), noidx(ref["node_idx"])) and np.array_equal(got["node_d2"], ref["node_d2"]), tag
+        assert np.array_equal(got["ctrl_idx"].astype(np.int64), noidx(ref["ctrl_idx"])) and np.array_equal(got["ctrl_d2"], ref["ctrl_d2"]), tag
+        assert np.array_equal(got["sample_idx"][same].astype(np.int64), noidx(ref["sample_idx"][same])), tag
+        assert np.array_equal(got["sample_d2"][same], ref["sample_d2"][same]), tag
+    return same
+
+
+def run_c5(E, oracle, window, frame, ticks, tunnel, want_nn, step=0.1):
+    c, m = E.Cloud(window), Mirror(window)
+    c.ring_index()
+    nfill = window // frame
+    for k in range(nfill):
+        f = S.c5_frame(k, frame, tunnel, step)
+        c.append(f)
+        m.append(f)
+    plan = E.ReplanPlan(c, S.C5_NODES, 128, S.C5_SEGMENTS)
+    hits = []
+    P = S.C5_PARAMS
+    for k in range(nfill, nfill + ticks):
+        f = S.c5_frame(k, frame, tunnel, step)
+        c.append(f)                                   # the plan stays valid: the ring index is updated in place
+        m.append(f)
+        start, nodes, coef, T, od = S.c5_tick_queries(k) if step == 0.1 else S.c5_tick_queries(int(round(k * step / 0.1)))
+        prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+        got = plan.run(prm, nodes, coef, T, od, 0.0, 2.0, 0.02, want_nn=want_nn)
+        ref = oracle.replan_tick(m.live(), start, P["sample_range"], P["search_margin"], P["max_radius"], nodes, coef, T, od, 0.0, 2.0, 0.02)
+        same = compare_tick(E, got, ref, len(nodes), want_nn, f"tick {k}")
+        # first hit: equal to the oracle's whenever no earlier sample's narrowed position differs
+        if same.all() or (ref["first_hit_sample"] >= 0 and same[:ref["first_hit_sample"] + 1].all()):
+            assert got["first_hit_sample"] == ref["first_hit_sample"], f"tick {k}"
+        hits.append((got["first_hit_sample"], got["first_hit_ctrl"], int((got["node_radius"] < 0).sum())))
+        # the un-captured entry points on the same cloud give the same numbers
+        if k == nfill:
+            bz = c.bezier_check(prm, coef, T, od, 0.0, 2.0, cap=128)
+            assert bz["first_hit"] == got["first_hit_sample"] and bz["n"] == got["nsamples"]
+            assert np.array_equal(bz["radius"], got["sample_radius"]) and np.array_equal(bz["pos"], got["sample_pos"])
+            cp = c.ctrl_points_check(prm, coef, T, od)
+            assert cp["first_hit"] == got["first_hit_ctrl"] and np.array_equal(cp["radius"], got["ctrl_radius"])
+            rad, idx, d2 = c.inflate(prm, nodes)
+            assert np.array_equal(rad, got["node_radius"])
+    plan.close()
+    c.close()
+    return hits
+
+
+@pytest.mark.parametrize("want_nn", [True, False])
+def test_replan_plan_ring_small(E, oracle, want_nn):
+    """C5 in miniature with a free corridor (tunnel variant): radii of both signs, some ticks collide, some do not"""
+    hits = run_c5(E, oracle, 300_000, 15_000, 8, tunnel=0.8, want_nn=want_nn)
+    assert any(h[2] not in (0, S.C5_NODES) for h in hits), "node radii should have both signs in the tunnel variant"
+
+
+def test_replan_plan_c5_full_size(E, oracle):
+    """Config C5 as BASELINE.json states it: 5,000,000-point rolling cloud, 50,000 points per frame (seed 8), per tick 64
+    corridor nodes + the 99-sample Bezier check + 21 control points (seed 9) through ONE captured graph, 20 ticks,
+    every radius / first hit / index against the exhaustive oracle on the same window"""
+    hits = run_c5(E, oracle, S.C5_WINDOW, S.C5_FRAME, 20, tunnel=0.0, want_nn=True)
+    assert len(hits) == 20
+
+
+def test_replan_plan_c5_full_size_free_corridor(E, oracle):
+    """the same window size with the corridor ahead of the drone free (radii of both signs), radius-only search"""
+    hits = run_c5(E, oracle, S.C5_WINDOW, S.C5_FRAME, 4, tunnel=1.0, want_nn=False)
+    assert any(h[0] == -1 for h in hits) or any(h[2] < S.C5_NODES for h in hits)
+
+
+def test_replan_plan_static_grid_and_recapture(E, oracle):
+    """the same plan over the cell-sorted index; a rebuilt grid (new cloud) makes the next run capture again by itself"""
+    P = S.C5_PARAMS
+    pts = np.concatenate([S.c5_frame(k, 20_000, 0.8) for k in range(10)])
+    c = E.Cloud(len(pts) + 50_000)
+    c.set_input(pts)
+    c.build_grid()
+    plan = E.ReplanPlan(c, S.C5_NODES, 128, S.C5_SEGMENTS)
+    live = pts
+    for k in (10, 11, 12):
+        if k == 11:                                   # a new frame arrives: the planner's setInput path (full replace + index rebuild)
+            live = np.concatenate([pts, S.c5_frame(k, 20_000, 0.8)])
+            c.set_input(live)
+            c.build_grid()
+        if k == 12:                                   # a large batch elsewhere reallocates the workspaces the old graph pointed at
+            c.nn(synth.uniform_points(5, 40_000, -30, 30))
+        start, nodes, coef, T, od = S.c5_tick_queries(k)
+        prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+        got = plan.run(prm, nodes, coef, T, od, 0.0, 2.0, 0.02, want_nn=True)
+        ref = oracle.replan_tick(live, start, P["sample_range"], P["search_margin"], P["max_radius"], nodes, coef, T, od, 0.0, 2.0, 0.02)
+        compare_tick(E, got, ref, len(nodes), True, f"tick {k}")
+    plan.close()
+    c.close()
+
+
+def test_nn_plan_survives_workspace_growth_and_rebuild(E, oracle):
+    """a captured NN plan used to replay kernels on freed workspaces after a larger batch, and on a stale index
+    after build_grid; the cloud's generation counter now makes pct_plan_run capture again"""
+    pts = synth.uniform_points(91, 150_000, 0, 50)
+    c = E.Cloud(200_000)
+    c.set_input(pts)
+    q = synth.uniform_points(92, 164, 0, 50)
+    plan = E.NNPlan(c, 164, E.ALGO_STREAM)             # qcap becomes 256
+    bi, bd = oracle.brute_nearest(pts, q)
+    i1, d1 = plan.run(q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    prm = E.inflate_params((25, 25, 25), 100.0, 0.25, 1.5)
+    c.inflate(prm, synth.uniform_points(93, 3000, 0, 50).astype(np.float64))      # 3000 > 256: every workspace is reallocated
+    i1, d1 = plan.run(q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    more = np.concatenate([pts, synth.uniform_points(94, 50_000, 0, 50)])
+    c.set_input(more)                                  # new point count
+    bi, bd = oracle.brute_nearest(more, q)
+    i1, d1 = plan.run(q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    plan.close()
+    plan = E.NNPlan(c, 164, E.ALGO_AUTO)
+    c.build_grid()                                     # AUTO now means the grid kernel, with pointers the old graph never saw
+    i1, d1 = plan.run(q)
+    assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    plan.close()
+    c.close()
+
+
+def test_ctrl_points_check_every_index_kind(E, oracle):
+    P = S.C5_PARAMS
+    pts = np.concatenate([S.c5_frame(k, 10_000, 0.6) for k in range(12)])
+    start, nodes, coef, T, od = S.c5_tick_queries(12)
+    T = np.float64([0.8, 1.0, 1.3])                    # unequal segment times: the control points scale per segment
+    prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+    for t_start in (0.0, 0.9):                         # 0.9 s lies in the second segment: its control points come first
+        ref = oracle.replan_tick(pts, start, P["sample_range"], P["search_margin"], P["max_radius"], nodes[:1], coef, T, od, t_start, 2.0, 0.02)
+        for kind in ("none", "grid", "ring"):
+            c = E.Cloud(len(pts))
+            if kind == "ring":
+                c.ring_index()
+            c.set_input(pts)
+            if kind == "grid":
+                c.build_grid()
+            cp = c.ctrl_points_check(prm, coef, T, od, t_start)
+            assert cp["n"] == ref["nctrl"] and cp["first_hit"] == ref["first_hit_ctrl"], (kind, t_start)
+            assert np.array_equal(cp["pos"], ref["ctrl_pos"]) and np.array_equal(cp["radius"], ref["ctrl_radius"]), (kind, t_start)
+            assert np.array_equal(cp["d2"], ref["ctrl_d2"]), (kind, t_start)
+            c.close()
