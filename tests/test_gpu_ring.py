@@ -74,7 +74,7 @@ def test_ring_index_irregular_appends(E, oracle):
     rad, idx, d2 = c.inflate(prm, pts)
     orad, oidx, od2 = oracle.inflate_brute(m.live(), (20.0, 20.0, 20.0), 18.0, 0.25, 1.5, pts)
     assert np.array_equal(rad, orad) and np.array_equal(d2, od2)
-    assert np.array_equal(idx.astype(np.int64), np.where(oidx < 0, E.NO_INDEX, oidx).astype(np.int64))
+    assert np.array_equal(idx.astype(np.int64), np.where(oidx < 0, np.int64(E.NO_INDEX), oidx.astype(np.int64)))
     rad2, idx2, d22 = c.inflate(prm, pts[:200])      # express size (mapped memory)
     assert np.array_equal(rad2, orad[:200]) and np.array_equal(d22, od2[:200])
     c.close()
@@ -126,7 +126,7 @@ def compare_tick(E, got, ref, nodes_n, want_nn, tag):
     same = np.all(got["sample_pos"].astype(np.float32) == ref["sample_pos"].astype(np.float32), axis=1)
     assert np.array_equal(got["sample_radius"][same], ref["sample_radius"][same]), f"{tag}: sample radii"
     if want_nn:
-        noidx = lambda a: np.where(a < 0, E.NO_INDEX, a).astype(np.int64)
+        noidx = lambda a: np.where(a < 0, np.int64(E.NO_INDEX), a.astype(np.int64))
         assert np.array_equal(got["node_idx"].astype(np.int64), noidx(ref["node_idx"])) and np.array_equal(got["node_d2"], ref["node_d2"]), tag
         assert np.array_equal(got["ctrl_idx"].astype(np.int64), noidx(ref["ctrl_idx"])) and np.array_equal(got["ctrl_d2"], ref["ctrl_d2"]), tag
         assert np.array_equal(got["sample_idx"][same].astype(np.int64), noidx(ref["sample_idx"][same])), tag
