@@ -3,19 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic queries: the batched 1-NN
-(pct_nn_batch_dev, include/pct_engine.h) of Q queries against the cloud resident in HBM.
-Workload at N=1 (config C3-throughput of SURVEY.md section 8(d)): 10,000,000 uniform points in
-[0,100)^3 (seed 3), Q = 1,048,576 uniform queries (seed 5), cell-pruned kernel (device-side query
-binning + nn_grid_coop_kernel).
-At N>1 (weak scaling): the cloud grows to N x 10M points at constant
-density, rank r owns the contiguous index range [r*10M, (r+1)*10M) in its own HBM, the query
-batch is replicated, every rank runs the same kernel on its shard and ONE exchange step
-(RCCL all_reduce(min) on fp64 d2, then all_reduce(min) on the matching indices) merges them.
+A "step" is one pass of the hot path over one batch of synthetic queries: the batched 1-NN (pct_nn_batch_dev,
+include/pct_engine.h) of Q = 1,048,576 queries (seed 5) against the cloud resident in HBM, cell-pruned kernel
+(device-side query binning + nn_grid_coop_kernel).
 
-Reported `value` = ranks x Q / t: (query, 10M-point shard) evaluations per second, i.e. queries/s
-in units of the metric's 10M-point cloud; `config.answered_queries_per_s` = Q / t is the rate of
-merged answers against the whole N x 10M cloud.  At N=1 both are the same number.
+N = 1 (config C3-throughput of SURVEY.md section 8(d), the configuration the metric is quoted on): 10,000,000 uniform points in
+[0,100)^3 (seed 3).
+N > 1 (config C4, STRONG scaling): ONE cloud of 100,000,000 uniform points in [0,200)^3 (seed 6); rank r owns the contiguous
+index range [r*1e8/N, (r+1)*1e8/N) in its own HBM; the query batch (seed 5, scaled to the box) is replicated; every rank
+answers it on its shard and ONE exchange step (RCCL all_reduce(min) on fp64 d2, then all_reduce(min) on the matching global
+indices) merges them.  `value` = merged answers per second = Q * steps / elapsed (NOT multiplied by the rank count);
+`config.query_shard_evaluations_per_s` = N * value is the secondary figure.  The line also carries config C4's own batch
+(Q = 4096, seed 7) through the brute-force streaming kernels (the form whose per-rank work shrinks with the shard) and through
+the index, and -- on rank 0's card -- the same 1 M-query batch against the WHOLE 100 M-point cloud on one GPU, so the strong-
+scaling ratio can be read from one line.
+
+`python bench.py --gpus N` started without RANK / WORLD_SIZE in the environment launches its N ranks itself (child processes,
+one per GPU, started before the parent touches the GPU; a card count below N turns the run into a gloo rehearsal with several
+ranks per card).  Under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
 
 One JSON line on rank 0; see the field notes in DESIGN.md section 6.
 """
@@ -36,11 +41,11 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 
 def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command
-    (scripts/prof_bench.sh -> profiles/*_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes).
-    None when no summary is committed (PMC counters cannot be collected inside the timed run)."""
+    """(HBM bytes per launch, file) of `kernel` from the newest committed PMC summary of this same command
+    (scripts/prof_bench.sh -> profiles/*_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes, the gfx950 correction of
+    MI355X_MICROARCH.md).  (None, None) when no summary is committed (PMC counters cannot be collected inside the timed run)."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(f))
@@ -48,71 +53,77 @@ def measured_traffic(kernel: str):
             continue
         for k, v in d.items():
             if kernel in k and "<true>" not in k and "derived_hbm_traffic_bytes_per_launch" in v:   # <true> = instrumented twin
-                best = v["derived_hbm_traffic_bytes_per_launch"]
-    return best
+                best, src = v["derived_hbm_traffic_bytes_per_launch"], "profiles/" + os.path.basename(f)
+    return best, src
 
 
-def replan_probe(E, synth, window=5_000_000, frame=50_000, ticks=60):
-    """Config C5: rolling window of 5,000,000 points fed 50,000 per sensor frame
-    (uniform in a 60 m cube around a drone moving +0.1 m per frame along x, seed 8), oldest frame evicted.
-    Per tick, through the host-buffer entry points (PCIe + launch latency included), on the un-indexed
-    rolling cloud (brute-force kernels; the cloud changes every tick):
-      ingest   pct_cloud_append_aos of the new frame
-      corridor pct_inflate_batch of 64 corridor nodes (SafeRegionEvaluate's re-check, corridor_finder.cpp:829-835)
-      bezier   pct_bezier_check: 3 segments of order 6, dt 0.02 s over a 2.0 s horizon = 99 samples
-               (checkSafeTrajectory, sim_planning_demo.cpp:729-781)
-    Reported: p50 / p99 milliseconds per tick and per part."""
+def replan_probe(E, synth, ticks=200):
+    """Config C5: rolling window of 5,000,000 points fed 50,000 per sensor frame (uniform in a 60 m
+    cube around a drone moving +0.1 m per frame along x, seed 8), oldest frame evicted; the cloud keeps the rolling-map index
+    (pct_cloud_ring_index: appends update it in place).  Per tick, through the host-buffer entry points (PCIe + launch
+    latency included):
+      ingest   pct_cloud_append_aos of the new frame (H2D + evict + file)
+      replan   pct_plan_replan_run: ONE captured hipGraph = inflation of 64 corridor nodes (SafeRegionEvaluate's re-check,
+               corridor_finder.cpp:829-835) + the sampled Bezier check, 3 segments of order 6, dt 0.02 s over a 2.0 s horizon
+               = 99 samples (checkSafeTrajectory, sim_planning_demo.cpp:729-781) + the 21 control points
+    Reported: p50 / p99 milliseconds per tick and per part over `ticks` ticks; the same queries through the un-captured
+    brute-force entry points on an un-indexed copy of the window (round 1's path) for a few ticks beside it."""
+    import gc
     import numpy as np
+    from pointcloudtraj_amd import scenarios as S
+    window, frame = S.C5_WINDOW, S.C5_FRAME
+    P = S.C5_PARAMS
     cloud = E.Cloud(window)
-    pos = 0.0
-
-    def frame_pts(k):
-        p = synth.uniform_points(8, frame, -30.0, 30.0, offset=k * frame)
-        p[:, 0] += np.float32(0.1 * k)
-        p[:, 2] = np.abs(p[:, 2]) * np.float32(0.2)
-        return p
-
+    cloud.ring_index()
     nfill = window // frame
     for k in range(nfill - 2):
-        cloud.append(frame_pts(k))
-    orders = np.int32([6, 6, 6])
-    seg_time = np.float64([1.0, 1.0, 1.0])
-    t_ing, t_cor, t_bez = [], [], []
-    import gc
+        cloud.append(S.c5_frame(k))
+    plan = E.ReplanPlan(cloud, S.C5_NODES, 128, S.C5_SEGMENTS)
+    t_ing, t_rep, t_lib = [], [], []
+    first_hits = 0
     gc.collect()
     gc.disable()                                   # a generation-2 collection of the interpreter (40 ms) used to land in one tick
-    for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (workspaces, first launches)
-        x0 = 0.1 * k
-        new_frame = frame_pts(k)                  # the sensor's output: produced outside the timed region
+    for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (first launches)
+        new_frame = S.c5_frame(k)                  # the sensor's output: produced outside the timed region
+        start, nodes, coef, T, od = S.c5_tick_queries(k)
+        prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
         t0 = time.perf_counter()
         cloud.append(new_frame)
         t1 = time.perf_counter()
-        nodes = (synth.uniform_points(9, 64, -1.0, 1.0, offset=k * 64).astype(np.float64) * [8.0, 3.0, 1.0] + [x0 + 6.0, 0.0, 2.5])
-        prm = E.inflate_params((x0, 0.0, 2.5), 30.0, 0.25, 1.5)
-        cloud.inflate(prm, nodes)
+        r = plan.run(prm, nodes, coef, T, od, 0.0, 2.0, 0.02, want_nn=False, copy=False)
         t2 = time.perf_counter()
-        coef = np.zeros((3, 21))
-        ctrl = synth.uniform_points(9, 21, -0.3, 0.3, offset=1_000_000 + k * 21).astype(np.float64)
-        for sgm in range(3):
-            for d in range(3):
-                for j in range(7):
-                    w = (sgm + j / 6.0) / 3.0
-                    base = [x0 + 12.0 * w, 0.0, 2.5][d]
-                    coef[sgm, d * 7 + j] = (base + (ctrl[sgm * 7 + j, d] if 0 < j < 6 else 0.0)) / seg_time[sgm]
-        cloud.bezier_check(prm, coef, seg_time, orders, 0.0, 2.0, cap=128)
-        t3 = time.perf_counter()
         if k >= nfill:
-            t_ing.append(1e3 * (t1 - t0)); t_cor.append(1e3 * (t2 - t1)); t_bez.append(1e3 * (t3 - t2))
+            t_ing.append(1e3 * (t1 - t0)); t_rep.append(1e3 * (t2 - t1)); t_lib.append(plan.last_run_us())
+            first_hits += int(r["first_hit_sample"] >= 0)
     gc.enable()
-    tot = np.asarray(t_ing) + np.asarray(t_cor) + np.asarray(t_bez)
-    cloud.close()
+    info = cloud.ring_info()
+    plan.close()
+    tot = np.asarray(t_ing) + np.asarray(t_rep)
     pct = lambda a, q: float(np.percentile(a, q))
-    return {"what": "C5: 5,000,000-point rolling cloud, +50,000 points per tick, 64 corridor-node inflations + 99-sample Bezier check per tick, host buffers",
-            "ticks": ticks, "ms_per_tick_p50": pct(tot, 50), "ms_per_tick_p99": pct(tot, 99),
-            "ingest_ms_p50": pct(t_ing, 50), "corridor_inflate_ms_p50": pct(t_cor, 50), "bezier_check_ms_p50": pct(t_bez, 50),
-            "worst_tick": {"index": int(np.argmax(tot)), "ingest_ms": float(np.asarray(t_ing)[np.argmax(tot)]),
-                           "corridor_inflate_ms": float(np.asarray(t_cor)[np.argmax(tot)]), "bezier_check_ms": float(np.asarray(t_bez)[np.argmax(tot)])},
-            "budget_ms_at_20Hz": 50.0}
+    out = {"what": "C5: 5,000,000-point rolling cloud with the rolling-map index, +50,000 points per tick; per tick ONE captured hipGraph = "
+                   "64 corridor-node inflations + 99-sample Bezier check + 21 control points; host buffers",
+           "ticks": ticks, "ms_per_tick_p50": pct(tot, 50), "ms_per_tick_p99": pct(tot, 99),
+           "ingest_ms_p50": pct(t_ing, 50), "ingest_ms_p99": pct(t_ing, 99), "replan_graph_ms_p50": pct(t_rep, 50), "replan_graph_ms_p99": pct(t_rep, 99),
+           "worst_tick": {"index": int(np.argmax(tot)), "ingest_ms": float(np.asarray(t_ing)[np.argmax(tot)]), "replan_graph_ms": float(np.asarray(t_rep)[np.argmax(tot)])},
+           "replan_inside_library_us_p50": dict(zip(("fill", "graph_launch", "wait", "read_out"), [float(v) for v in np.percentile(np.asarray(t_lib), 50, axis=0)])),
+           "ticks_with_a_colliding_sample": first_hits, "ring_index": info, "budget_ms_at_20Hz": 50.0}
+    # round 1's path for comparison: the same window un-indexed, brute-force kernels, three separate calls
+    cloud.ring_drop()
+    t_old = []
+    for k in range(nfill + ticks, nfill + ticks + 12):
+        new_frame = S.c5_frame(k)
+        start, nodes, coef, T, od = S.c5_tick_queries(k)
+        prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+        t0 = time.perf_counter()
+        cloud.append(new_frame)
+        cloud.inflate(prm, nodes)
+        cloud.bezier_check(prm, coef, T, od, 0.0, 2.0, cap=128)
+        cloud.ctrl_points_check(prm, coef, T, od)
+        if k >= nfill + ticks + 2:
+            t_old.append(1e3 * (time.perf_counter() - t0))
+    out["unindexed_brute_force_ms_per_tick_p50"] = pct(t_old, 50)
+    cloud.close()
+    return out
 
 
 def parse():
@@ -120,7 +131,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000, help="points per GPU")
+    ap.add_argument("--points", type=int, default=10_000_000, help="points of the N = 1 cloud (config C3)")
+    ap.add_argument("--points-total", type=int, default=100_000_000, help="points of the N > 1 cloud (config C4), split over the ranks")
     ap.add_argument("--queries", type=int, default=1 << 20)
     ap.add_argument("--algo", choices=["grid", "stream"], default="grid")
     ap.add_argument("--cell", type=float, default=0.0, help="grid cell size (<=0: automatic)")
@@ -128,7 +140,41 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=0, help="points in the host kd-tree (0 = same as --points)")
     ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming / brute-force / corridor probes (0 = skip)")
     ap.add_argument("--replan-probe", type=int, default=1, help="config C5: rolling 5M-point cloud, 20 Hz replan ticks (0 = skip)")
+    ap.add_argument("--one-gpu-ref", type=int, default=1, help="N > 1: rank 0 also times the batch against the whole cloud on its one card (0 = skip)")
     return ap.parse_args()
+
+
+def self_launch(a) -> int:
+    """`bench.py --gpus N` without a launcher: start the N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment) BEFORE this process touches the GPU, pass rank 0's JSON line through, fail if any rank fails.  Fewer cards
+    than ranks = rehearsal: ranks share cards round-robin and exchange over gloo (RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        if ndev < a.gpus:
+            env.setdefault("PCT_DIST_BACKEND", "gloo")
+        child = os.environ.get("PCT_BENCH_CHILD") or os.path.abspath(__file__)      # test hook: a stand-in rank program (tests/test_bench_launch.py)
+        procs.append(subprocess.Popen([sys.executable, child, *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return 1
+    lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if not lines:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    print(lines[-1])
+    return 0
 
 
 def cpu_baseline(points_fn, n_points, queries, nq):
@@ -166,8 +212,22 @@ def cpu_baseline(points_fn, n_points, queries, nq):
     return out, order[idx.astype(np.int64)], q
 
 
+def timed_batches(sc, q, algo, reps, barrier):
+    """milliseconds per merged batch (sharded kernels + exchange), barrier + synchronize on both sides"""
+    for _ in range(2):
+        sc.nn_submit(q, algo)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sc.nn_submit(q, algo)
+    barrier()
+    return 1e3 * (time.perf_counter() - t0) / reps
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch   # before the engine: one HIP runtime per process (engine._preload_hip_runtime)
     from pointcloudtraj_amd import dist as D, engine as E, synth
     import torch.distributed as tdist
@@ -176,14 +236,17 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
     # one GPU per rank; PCT_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks on one card
-    dev = (local % max(torch.cuda.device_count(), 1)) if world > 1 else 0
-    n_total = a.points * world
-    side = 100.0 * (world ** (1.0 / 3.0))      # constant density as the cloud grows
+    ncards = max(torch.cuda.device_count(), 1)
+    dev = (local % ncards) if world > 1 else 0
+    c4 = world > 1
+    n_total = a.points_total if c4 else a.points
+    side = 200.0 if c4 else 100.0
+    cloud_seed = 6 if c4 else 3
     Q = a.queries
     algo = E.ALGO_GRID if a.algo == "grid" else E.ALGO_STREAM
 
     sc = D.ShardedCloud(n_total, rank, world, dev)
-    local_pts = synth.uniform_points(3, sc.end - sc.begin, 0.0, side, offset=sc.begin)
+    local_pts = synth.uniform_points(cloud_seed, sc.end - sc.begin, 0.0, side, offset=sc.begin)
     sc.set_input_local(local_pts)
     t0 = time.perf_counter()
     if algo == E.ALGO_GRID:
@@ -215,6 +278,7 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / a.steps
+    d2_keep, idx_keep = d2.clone(), idx.clone()       # the result slots are reused by the probes below
 
     # dominant-kernel time: HIP events the engine recorded on the launch stream around every launch of the TIMED region
     # (the engine keeps the last 64 pairs; with more steps than that, the most recent 64 of them)
@@ -234,45 +298,105 @@ def main():
     torch.cuda.synchronize()
     pts_scanned, runs = sc.cloud.last_work()
     sc.cloud.set_work_counters(False)
-    bytes_alg = 16 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else 12 * len(local_pts) * ((Q + 7) // 8) + 24 * Q
+    # 12 B per point scanned (3 x fp32) + 8 B per examined cell run + 12 B per query in + 12 B out
+    bytes_alg = 12 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else 12 * len(local_pts) * ((Q + 7) // 8) + 24 * Q
+    bytes_rec = 16 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else bytes_alg   # what the 16-byte {x,y,z,index} records move
     achieved = bytes_alg / (k_ms * 1e-3) / 1e9
+
+    # ---- N > 1: config C4's own batch (Q = 4096, seed 7) through both kernel families, merged ------------------------------
+    c4_legs = None
+    if c4:
+        q4 = torch.from_numpy(synth.uniform_points(7, 4096, 0.0, side)).to(sc.device)
+        brute_ms = timed_batches(sc, q4, E.ALGO_STREAM, 3, barrier)
+        index_ms = timed_batches(sc, q4, E.ALGO_GRID, 10, barrier) if algo == E.ALGO_GRID else None
+        c4_legs = {"what": "C4 batch: 4096 NN queries (seed 7) against the sharded 100 M-point cloud, per-shard kernels + all_reduce(min) merge",
+                   "brute_force_ms_per_batch": brute_ms, "brute_force_pair_evals_per_s": 4096 * n_total / (brute_ms * 1e-3),
+                   "brute_force_merged_answers_per_s": 4096 / (brute_ms * 1e-3),
+                   "indexed_ms_per_batch": index_ms, "indexed_merged_answers_per_s": (4096 / (index_ms * 1e-3)) if index_ms else None}
+    one_gpu = None
+    if c4 and a.one_gpu_ref:
+        # strong-scaling base in the same run: rank 0's card alone holds the WHOLE cloud and answers the same batch
+        if rank == 0:
+            with E.Cloud(n_total) as whole:
+                off = 0
+                first = True
+                for o, blk in synth.uniform_points_chunked(cloud_seed, n_total, 0.0, side):
+                    (whole.set_input if first else whole.append)(blk)
+                    first = False
+                whole.build_grid(a.cell)
+                whole.reserve_queries(Q)
+                cs0 = torch.cuda.current_stream().cuda_stream
+                oi = torch.empty(Q, dtype=torch.int32, device=sc.device)
+                od = torch.empty(Q, dtype=torch.float64, device=sc.device)
+                for _ in range(3):
+                    whole.nn_device(q.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs0, E.ALGO_GRID)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    whole.nn_device(q.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs0, E.ALGO_GRID)
+                torch.cuda.synchronize()
+                one_ms = 1e3 * (time.perf_counter() - t1) / a.steps
+                same = bool(torch.equal(od, d2_keep) and torch.equal(oi, idx_keep.to(torch.int32)))
+                one_gpu = {"what": "the same batch against the whole cloud resident on ONE card (rank 0), cell-pruned kernel",
+                           "ms_per_step": one_ms, "answers_per_s": Q / (one_ms * 1e-3), "same_answers_as_sharded": same}
+        barrier()
 
     if rank != 0:
         if world > 1:
             tdist.destroy_process_group()
         return
 
+    traffic, traffic_src = measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel")
+    if c4:
+        traffic, traffic_src = None, None            # the committed PMC passes are of the N = 1 command
+    value = Q / elapsed * a.steps                    # merged answers per second (never multiplied by the rank count)
     out = {
         "metric": "nn_queries_per_sec_10M_point_cloud",
-        "value": world * Q / elapsed * a.steps,
+        "value": value,
         "unit": "queries/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if c4 else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"C3-throughput: {a.points} uniform fp32 points per GPU in [0,{side:.1f})^3 (seed 3), "
-                        f"{Q} uniform NN queries per step (seed 5), {a.algo} kernel, inputs resident in HBM",
-            "points_per_gpu": a.points, "total_points": n_total, "queries_per_step": Q, "algo": a.algo,
-            "answered_queries_per_s": Q / elapsed * a.steps,
-            "parallelism": f"cloud sharded by contiguous index range over {world} GPU(s), queries replicated, "
-                           "all_reduce(min) merge" if world > 1 else "single GPU",
+            "workload": (f"C4: ONE cloud of {n_total} uniform fp32 points in [0,{side:.0f})^3 (seed 6) sharded by contiguous index range over {world} "
+                         f"GPU(s) ({sc.end - sc.begin} points on rank 0), {Q} uniform NN queries per step (seed 5) replicated, {a.algo} kernel per shard, "
+                         "all_reduce(min) merge; value = merged answers/s"
+                         if c4 else
+                         f"C3-throughput: {a.points} uniform fp32 points in [0,{side:.1f})^3 (seed 3), "
+                         f"{Q} uniform NN queries per step (seed 5), {a.algo} kernel, inputs resident in HBM"),
+            "points_per_gpu": sc.end - sc.begin, "total_points": n_total, "queries_per_step": Q, "algo": a.algo,
+            "query_shard_evaluations_per_s": world * value,
+            "parallelism": (f"cloud sharded by contiguous index range over {world} GPU(s), queries replicated, all_reduce(min) merge"
+                            if world > 1 else "single GPU"),
+            "backend": tdist.get_backend() if world > 1 else None,
+            "cards": ncards,
             "grid": sc.cloud.grid_info() if sc.cloud.has_grid else None,
             "grid_build_s": round(t_grid, 4),
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel"),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "frac_of_measured_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "kernel": "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel",
-            "kernel_ms": k_ms, "kernel_launches_timed": len(kern_ms), "batch_kernels_ms": b_ms, "algorithmic_bytes": int(bytes_alg), "points_scanned": int(pts_scanned),
-            "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
+            "kernel_ms": k_ms, "kernel_launches_timed": len(kern_ms), "batch_kernels_ms": b_ms,
+            "algorithmic_bytes": int(bytes_alg), "algorithmic_bytes_rule": "SURVEY 8(d): 12 B x points scanned + 8 B x cell runs + 24 B x Q",
+            "record_bytes": int(bytes_rec), "achieved_with_16B_records": bytes_rec / (k_ms * 1e-3) / 1e9,
+            "points_scanned": int(pts_scanned), "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
+            "note": ("gather kernel: `frac` = algorithmic bytes / kernel time / 8 TB/s; the 10 M-point cloud (160 MB cell-sorted) stays in the 256 MiB "
+                     "Infinity Cache, so the bytes that reach the fabric are `traffic` (frac_of_measured_traffic); the DRAM-resident figures are in "
+                     "c4_probe (100 M-point cloud) and stream_probe"),
         },
     }
+    if c4_legs:
+        out["c4_q4096"] = c4_legs
+    if one_gpu:
+        out["one_gpu_whole_cloud"] = dict(one_gpu, speedup_of_this_run=value / one_gpu["answers_per_s"])
 
     if a.stream_probe and world == 1:
         cs = torch.cuda.current_stream().cuda_stream
@@ -384,7 +508,8 @@ def main():
         del d_pts
 
     if a.replan_probe and world == 1:
-        # config C4 on ONE card: the whole 100 M-point cloud (seed 6, [0,200)^3) resident, Q = 4096 (seed 7), host buffers
+        # config C4 on ONE card: the whole 100 M-point cloud (seed 6, [0,200)^3) resident -- 1.2 GB SoA + 1.6 GB cell-sorted, far
+        # beyond the 256 MiB Infinity Cache, so these are the DRAM-resident figures of both kernel families
         p4 = synth.uniform_points(6, 100_000_000, 0.0, 200.0)
         q4 = synth.uniform_points(7, 4096, 0.0, 200.0)
         with E.Cloud(len(p4)) as c4:
@@ -403,10 +528,49 @@ def main():
             t5 = time.perf_counter()
             ib, db = c4.nn(q4[:512], E.ALGO_STREAM)
             t6 = time.perf_counter()
-        out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted), 4096 NN queries, host buffers",
-                           "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_batch_ms": float(np.median(ts)),
+            # (a) streaming kernel, one pass over 1.2 GB of SoA per launch
+            cs4 = torch.cuda.current_stream().cuda_stream
+            c4.reserve_queries(Q)
+            qd = torch.from_numpy(synth.uniform_points(5, Q, 0.0, 200.0)).to(sc.device)
+            oi = torch.empty(Q, dtype=torch.int32, device=sc.device)
+            od = torch.empty(Q, dtype=torch.float64, device=sc.device)
+            sp = []
+            for qn in (1, 2, 4):
+                ms = []
+                for k in range(8):
+                    c4.nn_device(qd.data_ptr(), qn, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_STREAM)
+                    if k >= 2:
+                        ms.append(c4.last_kernel_ms())
+                m = float(np.median(ms))
+                sb = 12 * len(p4) + 24 * qn
+                sp.append({"queries": qn, "kernel_ms": m, "algorithmic_bytes": sb, "achieved_GBs": sb / (m * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": sb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            # (b) the 1 M-query throughput batch through the index
+            for _ in range(2):
+                c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+            torch.cuda.synchronize()
+            t7 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+            torch.cuda.synchronize()
+            step4 = 1e3 * (time.perf_counter() - t7) / reps
+            k4 = float(np.mean(c4.kernel_ms_history(reps)))
+            c4.set_work_counters(True)
+            c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+            torch.cuda.synchronize()
+            ps4, runs4 = c4.last_work()
+            c4.set_work_counters(False)
+            alg4 = 12 * ps4 + 8 * runs4 + 24 * Q
+            del qd, oi, od
+        out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted, beyond the 256 MiB Infinity Cache)",
+                           "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_4096_queries_ms_host_buffers": float(np.median(ts)),
                            "brute_force_512_queries_ms": 1e3 * (t6 - t5), "brute_force_pair_evals_per_s": 512 * 1e8 / (t6 - t5),
-                           "indexed_equals_brute_force": bool(np.array_equal(ib, i4[:512]) and np.array_equal(db, d4[:512]))}
+                           "indexed_equals_brute_force": bool(np.array_equal(ib, i4[:512]) and np.array_equal(db, d4[:512])),
+                           "stream_kernel": {"kernel": "nn_stream_kernel<QT> (all-fp64, one pass over the SoA cloud)", "points": sp},
+                           "grid_throughput": {"queries": Q, "ms_per_step": step4, "queries_per_s": Q / (step4 * 1e-3), "kernel": "nn_grid_coop_kernel",
+                                               "kernel_ms": k4, "algorithmic_bytes": int(alg4), "achieved_GBs": alg4 / (k4 * 1e-3) / 1e9,
+                                               "frac_of_hbm_peak": alg4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "points_scanned": int(ps4), "cell_runs": int(runs4)}}
         del p4
 
     if a.cpu_queries > 0 and world == 1:
@@ -414,7 +578,7 @@ def main():
         base, cpu_idx, cq = cpu_baseline(lambda: local_pts[:ncpu], ncpu, q_host, min(a.cpu_queries, Q))
         out["cpu_baseline"] = base
         if ncpu == a.points:     # same cloud: the GPU answers must equal the host kd-tree's (parity in the bench run itself)
-            gi = idx[:len(cq)].cpu().numpy()
+            gi = idx_keep[:len(cq)].cpu().numpy()
             out["cpu_baseline"]["gpu_matches_cpu_indices"] = bool(np.array_equal(gi, cpu_idx))
         if "corridor_replan_probe" in out:   # the same corridor scenario on the CPU restatement (oracle/rrt_port.c + kd-tree port), one core
             from oracle import oracle as O

@@ -238,6 +238,8 @@ int pct_plan_create_replan(pct_cloud *c, int32_t max_nodes, int32_t max_samples,
 /* traj may be NULL (corridor nodes only) */
 int pct_plan_replan_run(pct_plan *p, const pct_inflate_params *prm, const double *nodes, int64_t n_nodes, const pct_bezier_traj *traj,
                         double t_start, double stop_time, double dt, int want_nn, pct_replan_out *out);
+/* host wall time of the last pct_plan_replan_run in microseconds: {argument fill, hipGraphLaunch, wait for results, read-out} */
+int pct_plan_last_run_us(pct_plan *p, double us[4]);
 
 /* ---- measurement hooks (bench.py): HIP events recorded on the stream the kernels ran on.
  * pct_last_kernel_ms: the last batch's DOMINANT kernel alone (nn_grid_kernel, nn_tile_filter_kernel

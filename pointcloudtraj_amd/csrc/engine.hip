@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -194,6 +195,7 @@ struct pct_plan {
     uint64_t generation = 0;                     // the cloud's generation the graph was captured at
     int algo = 0;
     ReplanCtx *rx = nullptr;
+    double run_us[4] = { 0, 0, 0, 0 };
     pct_cloud *c = nullptr;
     int64_t Q = 0;
     float *h_q = nullptr;

@@ -150,7 +150,12 @@ class ShardedCloud:
         (d2, idx, done_event).  The next batch's kernels therefore overlap this batch's all_reduce pair
         (8+4 bytes per query over xGMI, which at Q = 1M costs about as much as the kernels).  The consumer waits
         on done_event (torch.cuda.current_stream().wait_event(ev) or ev.synchronize()) before reading; with a single rank
-        done_event is None and the results are simply ordered on the current stream."""
+        done_event is None and the results are simply ordered on the current stream.
+
+        Index contract, the same on every branch (one rank, RCCL, gloo rehearsal): int32 global indices (int64 once the cloud
+        holds 2^31 - 1 points or more), -1 = no point anywhere (every shard empty).  The returned tensors live in this
+        batch's result slot: they stay valid until the `depth`-th later submit, whose kernels first wait for this batch's
+        exchange (slot_free event) -- a consumer that needs them longer copies them after waiting on done_event."""
         if self.world == 1:
             # nothing to merge: hand back the engine's own buffers (idx = the u32 indices as an int32 view, no
             # conversion kernel in the step; PCT_NO_INDEX reads as -1)
@@ -173,6 +178,7 @@ class ShardedCloud:
             staged = idx.is_cuda and dist.get_backend(self.group) == "gloo" and os.environ.get("PCT_DIST_DEVICE_COLLECTIVES") != "1"
             if staged:
                 best, cand = merge_nearest(d2, idx, self.group)         # rehearsal: staged through the host
+                cand = self._normalise(cand, idx.dtype == torch.int32)
             elif idx.dtype == torch.int32:
                 # RCCL, indices < 2^31: copy + all_reduce(min) on d2, ONE fused mask kernel (pct_merge_mask_dev), all_reduce(min)
                 # on the masked indices -- into this slot's preallocated buffers (valid until the slot is reused, i.e. until the
@@ -183,14 +189,23 @@ class ShardedCloud:
                 dist.all_reduce(best, op=dist.ReduceOp.MIN, group=self.group)
                 self.E.merge_mask_device(d2.data_ptr(), best.data_ptr(), idx32.data_ptr(), cand.data_ptr(), Q, self._comm.cuda_stream)
                 dist.all_reduce(cand, op=dist.ReduceOp.MIN, group=self.group)
+                cand.masked_fill_(cand == torch.iinfo(torch.int32).max, -1)      # on the exchange stream, off the kernels' path
             else:
                 best, cand = _merge_nearest(d2, idx, self.group)
+                cand = self._normalise(cand, False)
             done = torch.cuda.Event()
             done.record(self._comm)
         self._slot_free[slot] = done
         best.record_stream(cur)
         cand.record_stream(cur)
         return best, cand, done
+
+    @staticmethod
+    def _normalise(cand: torch.Tensor, narrow: bool) -> torch.Tensor:
+        """merged indices of merge_nearest / _merge_nearest (int64, 0xFFFFFFFF or INT64_MAX = none) -> nn_submit's contract"""
+        none = (cand == 0xFFFFFFFF) | (cand == _I64_MAX)
+        cand = torch.where(none, torch.full_like(cand, -1), cand)
+        return cand.to(torch.int32) if narrow else cand
 
     def nn(self, q: torch.Tensor, algo: int = 0):
         d2, idx = self.nn_local(q, algo)

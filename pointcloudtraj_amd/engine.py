@@ -107,6 +107,7 @@ def lib():
         L.pct_ctrl_points_check.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.POINTER(i64), C.POINTER(i64),
                                             i64, f64p, f64p, f64p, u32p]
         L.pct_plan_create_replan.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.pct_plan_last_run_us.argtypes = [vp, C.POINTER(C.c_double)]
         L.pct_plan_replan_run.argtypes = [vp, C.POINTER(InflateParams), f64p, i64, C.POINTER(BezierTraj), C.c_double, C.c_double, C.c_double,
                                           C.c_int, C.POINTER(ReplanOut)]
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
@@ -407,6 +408,12 @@ class ReplanPlan:
                     sample_radius=cp(b["sample_radius"][:ns]), sample_d2=cp(b["sample_d2"][:ns]), sample_idx=cp(b["sample_idx"][:ns]),
                     nctrl=nc, first_hit_ctrl=o.first_hit_ctrl, ctrl_pos=cp(b["ctrl_pos"][:nc]), ctrl_radius=cp(b["ctrl_radius"][:nc]),
                     ctrl_d2=cp(b["ctrl_d2"][:nc]), ctrl_idx=cp(b["ctrl_idx"][:nc]))
+
+    def last_run_us(self):
+        """host wall time of the last run inside the library: (fill, graph launch, wait, read-out) in microseconds"""
+        us = (C.c_double * 4)()
+        _chk(lib().pct_plan_last_run_us(self._h, us))
+        return tuple(us)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value and _lib is not None:

@@ -94,3 +94,24 @@ def test_fused_merge_mask_equals_the_elementwise_recipe():
     E.merge_mask_device(d_m.data_ptr(), d_b.data_ptr(), d_i32.data_ptr(), out.data_ptr(), Q, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), want)
+
+
+def test_bench_two_ranks_on_one_card():
+    """`python bench.py --gpus 2` started plainly (no launcher, no RANK in the environment) must start its two ranks itself and
+    print ONE line with n_gpus = 2 and the C4 workload (strong scaling, merged answers/s); on this one-card box the ranks share
+    the card and exchange over gloo (rehearsal).  Reduced sizes: the point of the test is the launch path and the line's shape."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points-total", "4000000",
+                        "--queries", "65536"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["total_points"] == 4000000
+    assert d["config"]["points_per_gpu"] == 2000000 and d["config"]["backend"] == "gloo"
+    assert abs(d["config"]["query_shard_evaluations_per_s"] - 2 * d["value"]) < 1e-6 * d["value"]
+    assert d["one_gpu_whole_cloud"]["same_answers_as_sharded"] is True
+    assert d["c4_q4096"]["brute_force_ms_per_batch"] > 0
