@@ -131,9 +131,12 @@ struct pct_cloud {
     size_t bins_cap = 0;
     uint32_t *d_qbin = nullptr, *d_perm = nullptr;                              // sized by reserve_queries
     float4 *d_qsorted = nullptr;
+    uint32_t *d_inv = nullptr, *d_sres_idx = nullptr;                           // inverse permutation and sorted-order results
+    double *d_sres_d2 = nullptr;
     float4 *d_sorttmp = nullptr;                                                // {x,y,z,id} records of the two-level sort
     uint32_t *d_sortkey = nullptr;                                              // their keys
-    uint32_t *d_sort1 = nullptr;                                                // total1 | start1(+1) | fill1
+    uint32_t *d_sort1 = nullptr;                                                // total1 | start1(+1) | fill1 | total1 (second set)
+    int sort_phase = 0;                                                         // which set of totals the next batch adds into
     // query workspaces
     int64_t qcap = 0;
     float *d_q = nullptr, *d_r = nullptr;
@@ -406,6 +409,12 @@ int nn_stream_q64(pct_cloud *c, int64_t Q, uint32_t *d_idx, double *d_d2, hipStr
     return PCT_OK;
 }
 
+bool lds_sort_on()
+{
+    static const bool v = [] { const char *e = std::getenv("PCT_LDS_SORT"); return e ? std::atoi(e) != 0 : true; }();
+    return v;
+}
+
 // counting sort of the batch by coarse cell -> c->d_perm (nullptr result = keep arrival order)
 int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const uint32_t **perm_out)
 {
@@ -414,12 +423,16 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
     if (const char *e = std::getenv("PCT_SORT_MIN_Q")) min_q = std::atoll(e);
     if (Q < min_q) return PCT_OK;
     const BinDesc &B = c->B;
-    static const bool lds_sort = [] { const char *e = std::getenv("PCT_LDS_SORT"); return e ? std::atoi(e) != 0 : true; }();
-    if (lds_sort) {
+    if (lds_sort_on()) {
         // two-level counting sort on LDS histograms (kernels.hpp)
         int key_shift = 0;
         while ((((uint64_t)B.nbins - 1) >> key_shift) >= (1ull << 20)) key_shift++;
-        uint32_t *total1 = c->d_sort1, *start1 = c->d_sort1 + kSortBuckets, *fill1 = c->d_sort1 + 2 * kSortBuckets + 4;
+        // two sets of bucket totals used in turn: a batch's histogram pass zeroes the set the NEXT batch will add into (a captured
+        // graph replays one set, so it keeps the memset behind its scatter pass instead)
+        static const bool pingpong_on = [] { const char *e = std::getenv("PCT_SORT_PINGPONG"); return e ? std::atoi(e) != 0 : true; }();
+        const bool pingpong = pingpong_on && !c->capturing;
+        uint32_t *total1 = c->d_sort1 + (c->sort_phase ? 3 * kSortBuckets + 8 : 0), *start1 = c->d_sort1 + kSortBuckets, *fill1 = c->d_sort1 + 2 * kSortBuckets + 4;
+        uint32_t *total1_next = c->d_sort1 + (c->sort_phase ? 0 : 3 * kSortBuckets + 8);
         // PCT_SORT_LEVELS: 1 (default) = one counting pass into <= 1024 spatial buckets, queries left in arrival order inside a
         // bucket; 2 = a second pass orders every bucket by the remaining key bits.  With the block-first search the finer order
         // no longer pays for its pass (same-box: 0.198-0.204 ms per step with it, 0.168 without).
@@ -432,13 +445,17 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         const uint32_t per_block = per_block_env ? (uint32_t)per_block_env
                                                  : (uint32_t)std::min<int64_t>(kSortPerBlock, std::max<int64_t>(1024, (Q / 128 + 1023) / 1024 * 1024));
         const int nb = ceil_div(Q, (int64_t)per_block);
-        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, per_block, c->d_qbin, total1, fill1);
+        // the key array costs 4 B per query written by one pass and read by the next: the scatter pass recomputes keys instead
+        static const bool store_keys = [] { const char *e = std::getenv("PCT_SORT_STORE_KEYS"); return e ? std::atoi(e) != 0 : false; }();
+        uint32_t *keys = store_keys ? c->d_qbin : nullptr;
+        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, per_block, keys, total1, fill1, pingpong ? total1_next : nullptr);
         if (levels == 1) {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, c->d_perm);
-            HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));       // the fine pass would have re-zeroed it
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, c->d_perm, c->d_inv);
+            if (pingpong) c->sort_phase ^= 1;
+            else HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));   // the fine pass would have re-zeroed it
         } else {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->d_qbin, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr);
-            qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, c->d_perm, c->d_qsorted);
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr, nullptr);
+            qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, c->d_perm, c->d_qsorted, c->d_inv);
         }
         HIPCHK(hipGetLastError());
         *perm_out = c->d_perm;
@@ -578,12 +595,25 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         dom_begin(c, s);
         if (coop) {   // 8 lanes per query (default)
             const int blocks = ceil_div(Q, 256 / kCoop);
+            // sorted batches: the kernel writes its results in sorted order (full lines) and one gather pass puts them back into
+            // arrival order -- scattering 4 + 8 bytes per query from here cost 5.6x the result bytes in fabric writes
+            static const bool sorted_writes = [] { const char *e = std::getenv("PCT_SORTED_WRITES"); return e ? std::atoi(e) != 0 : false; }();
+            const bool so = perm != nullptr && sorted_writes && lds_sort_on();
+            uint32_t *k_idx = so ? c->d_sres_idx : d_idx;
+            double *k_d2 = so ? c->d_sres_d2 : d_d2;
             if (c->count_work)
                 nn_grid_coop_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
-                                                                  perm ? c->d_qsorted : nullptr, d_idx, d_d2, c->d_work);
+                                                                  perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
             else
                 nn_grid_coop_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
-                                                                   perm ? c->d_qsorted : nullptr, d_idx, d_d2, c->d_work);
+                                                                   perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
+            if (so) {
+                dom_end(c, s);
+                unpermute_results_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->d_inv, c->d_sres_idx, c->d_sres_d2, (uint32_t)Q, d_idx, d_d2);
+                end_timing(c, s);
+                HIPCHK(hipGetLastError());
+                return PCT_OK;
+            }
         } else if (c->count_work)
             nn_grid_kernel<true><<<ceil_div(Q, 256), 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q,
                                                                    (uint32_t)c->index_base, perm, d_idx, d_d2, c->d_work);
@@ -795,6 +825,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
+    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf);
@@ -897,6 +928,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
+    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2);
     c->qcap = 0;
     c->generation++;                    // captured plans hold these pointers
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
@@ -915,9 +947,12 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_qsorted, q));
     PCTCHK(dev_alloc(&c->d_sorttmp, q));
     PCTCHK(dev_alloc(&c->d_sortkey, q));
+    PCTCHK(dev_alloc(&c->d_inv, q));
+    PCTCHK(dev_alloc(&c->d_sres_idx, q));
+    PCTCHK(dev_alloc(&c->d_sres_d2, q));
     if (!c->d_sort1) {
-        PCTCHK(dev_alloc(&c->d_sort1, 3 * kSortBuckets + 8));
-        HIPCHK(hipMemset(c->d_sort1, 0, sizeof(uint32_t) * (3 * kSortBuckets + 8)));   // the sort keeps total1 zero between batches
+        PCTCHK(dev_alloc(&c->d_sort1, 4 * kSortBuckets + 8));
+        HIPCHK(hipMemset(c->d_sort1, 0, sizeof(uint32_t) * (4 * kSortBuckets + 8)));   // the sort keeps both sets of totals zero between batches
     }
     c->part_q = std::min<int64_t>(q, kPartQueries);
     PCTCHK(dev_alloc(&c->d_part_d2, (size_t)c->part_q * kMaxParts));

@@ -1011,11 +1011,15 @@ constexpr int kSortPerBlock = 1024 * kSortItems;      // most queries per block 
 // kernel or, in single-level mode, a memset behind scatter1), fill1 is zeroed here, before any scatter1 block can touch it.
 __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, int lshift, const float *__restrict__ q,
                                                           uint32_t Q, uint32_t per_block, uint32_t *__restrict__ keys,
-                                                          uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1)
+                                                          uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1,
+                                                          uint32_t *__restrict__ total1_next)
 {
     __shared__ uint32_t h[kSortBuckets];
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < kSortBuckets; i += 1024) fill1[i] = 0;
+        for (int i = threadIdx.x; i < kSortBuckets; i += 1024) {
+            fill1[i] = 0;
+            if (total1_next) total1_next[i] = 0;      // the next batch's totals (its last reader finished a batch ago): no memset on the path
+        }
     for (int i = threadIdx.x; i < kSortBuckets; i += 1024) h[i] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * per_block;
@@ -1033,7 +1037,7 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
         const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
         if (k < items && t < Q) {
             const uint32_t key = query_bin(G, B, qv[k][0], qv[k][1], qv[k][2]) >> key_shift;
-            keys[t] = key;
+            if (keys) keys[t] = key;                 // nullptr: the scatter pass recomputes the key from the query it reads anyway
             atomicAdd(&h[key >> lshift], 1u);
         }
     }
@@ -1045,11 +1049,11 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
 // level 1 scatter: the query record {x, y, z, bitcast(id)} travels with its key, so the fine pass
 // never gathers from the (randomly ordered) input again.  Every block scans the 1024 bucket totals itself
 // (thread i = bucket i) instead of waiting for a one-block scan kernel; block 0 publishes the starts for the fine pass.
-__global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__restrict__ keys, const float *__restrict__ q,
+__global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDesc B, int key_shift, const uint32_t *__restrict__ keys, const float *__restrict__ q,
                                                               uint32_t Q, uint32_t per_block, int lshift, const uint32_t *__restrict__ total1,
                                                               uint32_t *__restrict__ fill1, uint32_t *__restrict__ start1,
                                                               uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec,
-                                                              uint32_t *__restrict__ perm)
+                                                              uint32_t *__restrict__ perm, uint32_t *__restrict__ inv)
 {
     static_assert(kSortBuckets == 1024, "one thread per bucket");
     __shared__ uint32_t h[kSortBuckets];
@@ -1081,8 +1085,13 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
     for (int k = 0; k < kSortItems; k++) {
         const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
         const bool ok = k < items && t < Q;
-        key[k] = ok ? keys[t] : 0xFFFFFFFFu;
+        key[k] = ok ? (keys ? keys[t] : 0u) : 0xFFFFFFFFu;
         qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
+    }
+    if (!keys) {
+#pragma unroll
+        for (int k = 0; k < kSortItems; k++)
+            if (key[k] != 0xFFFFFFFFu) key[k] = query_bin(G, B, qv[k][0], qv[k][1], qv[k][2]) >> key_shift;
     }
 #pragma unroll
     for (int k = 0; k < kSortItems; k++)
@@ -1101,6 +1110,7 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
             const uint32_t pos = basepos[key[k] >> lshift] + atomicAdd(&h[key[k] >> lshift], 1u);
             if (perm) perm[pos] = t;                  // single-level mode: this IS the final order
             else tmp_key[pos] = key[k];
+            if (inv) inv[t] = pos;                    // where query t went (coalesced): results come back through it
             tmp_rec[pos] = make_float4(qv[k][0], qv[k][1], qv[k][2], __uint_as_float(t));
         }
     }
@@ -1113,7 +1123,8 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(const uint32_t *__
 constexpr int kFineThreads = 1024;
 __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t *__restrict__ tmp_key, const float4 *__restrict__ tmp_rec,
                                                                   const uint32_t *__restrict__ start1, uint32_t *__restrict__ total1,
-                                                                  uint32_t lmask, uint32_t *__restrict__ perm, float4 *__restrict__ qsorted)
+                                                                  uint32_t lmask, uint32_t *__restrict__ perm, float4 *__restrict__ qsorted,
+                                                                  uint32_t *__restrict__ inv)
 {
     static_assert(kSortBuckets == kFineThreads, "one histogram entry per thread");
     __shared__ uint32_t h[kSortBuckets];
@@ -1145,7 +1156,21 @@ __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t
         const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & lmask], 1u);
         perm[pos] = __float_as_uint(rec.w);
         qsorted[pos] = rec;
+        if (inv) inv[__float_as_uint(rec.w)] = pos;
     }
+}
+
+// results of a sorted batch back into arrival order: out[t] = sorted[inv[t]] -- a gather from the 12 MB of sorted results
+// (cache resident) with coalesced writes, instead of 2 x Q scattered partial-line writes from the search kernel
+__global__ __launch_bounds__(256) void unpermute_results_kernel(const uint32_t *__restrict__ inv, const uint32_t *__restrict__ sidx,
+                                                                const double *__restrict__ sd2, uint32_t Q,
+                                                                uint32_t *__restrict__ out_idx, double *__restrict__ out_d2)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Q) return;
+    const uint32_t p = inv[t];
+    out_idx[t] = sidx[p];
+    out_d2[t] = sd2[p];
 }
 
 // =====================================================================================
@@ -1596,7 +1621,7 @@ __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const flo
                                                            const float *__restrict__ q, uint32_t Q, uint32_t index_base,
                                                            const float4 *__restrict__ qsorted,
                                                            uint32_t *__restrict__ out_idx, double *__restrict__ out_d2,
-                                                           WorkCounters *__restrict__ work)
+                                                           WorkCounters *__restrict__ work, int sorted_out)
 {
     const uint32_t sub = threadIdx.x & (kCoop - 1);
     const uint32_t bslot = qsorted ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -1607,7 +1632,7 @@ __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const flo
         float qxf, qyf, qzf;
         if (qsorted) {                                // binned batch: query and output slot in one record
             const float4 R = qsorted[slot];
-            qxf = R.x; qyf = R.y; qzf = R.z; t = __float_as_uint(R.w);
+            qxf = R.x; qyf = R.y; qzf = R.z; t = sorted_out ? slot : __float_as_uint(R.w);     // sorted_out: results stay in sorted order
         } else {
             qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
         }
