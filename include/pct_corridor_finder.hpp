@@ -19,6 +19,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -147,6 +150,7 @@ public:
     uint64_t speculativeHits() const { return n_spec_hit_; }
     uint64_t speculativeFallbacks() const { return n_spec_miss_; }
     uint64_t expansionLaunches() const { return n_launch_; }
+    uint64_t repairBatches() const { return n_repair_batches_; }      // GPU round trips of treeRepair: two per pass (was two per neighbour)
     void setFusedExpansion(bool on) { fused_ok_ = on; }          // off = nearest / inflation / range as three batched launches
 
     // :226-270
@@ -179,6 +183,7 @@ public:
     void SafeRegionExpansion(int64_t iterations)
     {
         kdTree_ = kd_create(3);
+        if (!kdTree_) throw std::runtime_error(std::string("kd_create: ") + pct_last_error());
         commit_root = start_pt;
         root_node = new CorridorNode(start_pt, (float)radiusSearch(start_pt), 0.0f, (float)min_distance);
         recordNode(root_node);
@@ -283,6 +288,13 @@ private:
         const double s[3] = { start_pt.x, start_pt.y, start_pt.z };
         map_.setStartPt(s);
     }
+    // kd_* return NULL on a device failure (and kd_nearest* on an empty tree): surface it as an exception the C ABI wrapper
+    // (csrc/corridor.cpp guarded()) turns into an error code, instead of dereferencing it
+    static kdres *must(kdres *r, const char *what)
+    {
+        if (!r) throw std::runtime_error(std::string(what) + " returned no result set: " + pct_last_error());
+        return r;
+    }
     double radiusSearch(const Vec3 &p)                      // :113-133 -> HIP inflation
     {
         const double q[3] = { p.x, p.y, p.z };
@@ -344,7 +356,7 @@ private:
     NodePtr findNearstVertex(const Vec3 &pt)                             // :428-437
     {
         float pos[3] = { (float)pt.x, (float)pt.y, (float)pt.z };
-        kdres *nearest = kd_nearestf(kdTree_, pos);
+        kdres *nearest = must(kd_nearestf(kdTree_, pos), "kd_nearestf");
         NodePtr n = (NodePtr)kd_res_item_data(nearest);
         kd_res_free(nearest);
         return n;
@@ -386,7 +398,7 @@ private:
     {
         float pos[3] = { (float)n->coord.x, (float)n->coord.y, (float)n->coord.z };
         n->kd_index = kdx_size(kdTree_);
-        kd_insertf(kdTree_, pos, n);
+        if (kd_insertf(kdTree_, pos, n) != 0) throw std::runtime_error(std::string("kd_insertf: ") + pct_last_error());
         syncNodeAux(n);
     }
     // what the fused expansion kernel's steer step reads for this node: fp64 centre, float radius (widened)
@@ -661,7 +673,7 @@ private:
         if (!presults) {
             const float range = newPtr->radius * 2.0f;
             float pos[3] = { (float)newPtr->coord.x, (float)newPtr->coord.y, (float)newPtr->coord.z };
-            presults = kd_nearest_rangef(kdTree_, pos, range);
+            presults = must(kd_nearest_rangef(kdTree_, pos, range), "kd_nearest_rangef");
         }
         std::vector<NodePtr> nearPtrList;
         bool isInvalid = false;
@@ -756,20 +768,69 @@ private:
         for (size_t i = 0; i < k; i++) { Path[k - 1 - i] = PathList[i]->coord; Radius[k - 1 - i] = PathList[i]->radius; }
         path_exist_status = true;
     }
+    // One batch per pass (corridor_finder.cpp:938-1021).  The reference asks, per failed node, one kd_nearest_rangef and then one
+    // radiusSearch per valid neighbour, each a launch + a host round trip here.  Neither the node tree nor the obstacle cloud changes
+    // inside the loop (nodes are only marked invalid; removeInvalid runs after it), and radiusSearch is a pure function of the
+    // neighbour's centre, so: ONE launch finds the neighbourhood candidates of every failed node, ONE launch inflates every node
+    // that could be re-checked, and the reference's per-node logic then runs on the host in its own order with those answers.
     void treeRepair(std::vector<std::pair<Vec3, double>> &node_list)                            // :938-1021
     {
-        for (auto &fail : node_list) {
-            const Vec3 center = fail.first;
-            const float range = (float)fail.second * 2.0f;
-            float pos[3] = { (float)center.x, (float)center.y, (float)center.z };
-            kdres *presults = kd_nearest_rangef(kdTree_, pos, range);
+        const int K = (int)node_list.size();
+        if (K == 0) { removeInvalid(); return; }
+        const int32_t n0 = kdx_size(kdTree_);
+        const int cap = 256;
+        std::vector<float> posf((size_t)3 * K), range((size_t)K);
+        for (int i = 0; i < K; i++) {
+            const Vec3 &c = node_list[(size_t)i].first;
+            posf[3 * (size_t)i] = (float)c.x; posf[3 * (size_t)i + 1] = (float)c.y; posf[3 * (size_t)i + 2] = (float)c.z;
+            range[(size_t)i] = (float)node_list[(size_t)i].second * 2.0f;
+        }
+        std::vector<kdres *> sets((size_t)K, nullptr);
+        struct Free { std::vector<kdres *> &v; ~Free() { for (auto r : v) if (r) kd_res_free(r); } } guard{ sets };
+        {
+            std::vector<uint32_t> ids((size_t)K * cap);
+            std::vector<int32_t> counts((size_t)K);
+            for (int b0 = 0; b0 < K; b0 += 1024) {             // kdx batches hold at most 1024 queries
+                const int m = std::min(1024, K - b0);
+                const bool ok = kdx_range_candidates_batch(kdTree_, &posf[3 * (size_t)b0], &range[(size_t)b0], m, &ids[(size_t)b0 * cap], cap, &counts[(size_t)b0]) == 0;
+                n_repair_batches_++;
+                for (int i = b0; i < b0 + m; i++)
+                    sets[(size_t)i] = must(ok && counts[(size_t)i] >= 0 ? kdx_range_from_candidates(kdTree_, &posf[3 * (size_t)i], range[(size_t)i], &ids[(size_t)i * cap], counts[(size_t)i], n0)
+                                                                        : kd_nearest_rangef(kdTree_, &posf[3 * (size_t)i], range[(size_t)i]), "kd_nearest_rangef");
+            }
+        }
+        // every node the loop below may re-check: in some failed node's neighbourhood, still valid, not the root nor its child
+        std::vector<NodePtr> cand;
+        for (int i = 0; i < K; i++) {
+            for (kd_res_rewind(sets[(size_t)i]); !kd_res_end(sets[(size_t)i]); kd_res_next(sets[(size_t)i])) {
+                NodePtr ptr = (NodePtr)kd_res_item_data(sets[(size_t)i]);
+                if (!ptr->valid || ptr->preNode_ptr == root_node || ptr == root_node || ptr->rel_id == -3) continue;
+                ptr->rel_id = -3;                              // scratch mark (restored below): listed once
+                cand.push_back(ptr);
+            }
+            kd_res_rewind(sets[(size_t)i]);
+        }
+        std::vector<double> coords(3 * cand.size()), radii(cand.size());
+        for (size_t k = 0; k < cand.size(); k++) {
+            cand[k]->rel_id = -2;
+            coords[3 * k] = cand[k]->coord.x; coords[3 * k + 1] = cand[k]->coord.y; coords[3 * k + 2] = cand[k]->coord.z;
+        }
+        if (!cand.empty()) { map_.checkRadiusBatch(coords.data(), (int64_t)cand.size(), radii.data()); n_repair_batches_++; }
+        std::unordered_map<NodePtr, double> fresh;
+        fresh.reserve(cand.size() * 2);
+        for (size_t k = 0; k < cand.size(); k++) fresh.emplace(cand[k], radii[k]);
+
+        for (int i = 0; i < K; i++) {
+            kdres *presults = sets[(size_t)i];
             while (!kd_res_end(presults)) {
                 NodePtr ptr = (NodePtr)kd_res_item_data(presults);
                 kd_res_next(presults);
                 if (!ptr->valid) continue;
                 NodePtr pre_ptr = ptr->preNode_ptr;
                 if (pre_ptr == root_node || ptr == root_node) continue;
-                const double update_radius = radiusSearch(ptr->coord);
+                const auto it = fresh.find(ptr);
+                const double update_radius = it != fresh.end() ? it->second : radiusSearch(ptr->coord);
+                if (it != fresh.end()) n_inflate_++;           // counted where the reference calls radiusSearch
                 const int ret = checkNodeUpdate(update_radius, ptr->radius);
                 ptr->radius = (float)update_radius;
                 syncNodeAux(ptr);
@@ -793,7 +854,6 @@ private:
                         clearBranchS(child);
                     }
             }
-            kd_res_free(presults);
         }
         removeInvalid();
     }
@@ -821,7 +881,7 @@ private:
     std::vector<Vec3> Path;
     std::vector<double> Radius;
     MinStdRand0 eng_;
-    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0, n_launch_ = 0;
+    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0, n_launch_ = 0, n_repair_batches_ = 0;
     bool fused_ok_ = true;          // one-launch expansion batches (kdx_expand_batch); false = the three-stage form
     int spec_k_ = 64;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
 };

@@ -53,15 +53,28 @@ public:
     // build_index: also build the cell index used by the batched queries (worth it for static clouds).
     void setInput(const void *points, int64_t n, int64_t stride_bytes = 16, bool build_index = true)
     {
-        if (n > capacity_) {   // grow: the reference accepts any cloud size
+        if (n > capacity_) {   // grow: the reference accepts any cloud size.  The larger cloud is created FIRST: if that fails
+            pct_cloud *bigger = nullptr;   // (check throws) the map keeps its old, valid cloud
+            const int64_t cap = n + n / 2;
+            check(pct_cloud_create(cap, &bigger), "pct_cloud_create");
+            if (rolling_ && pct_cloud_ring_index(bigger, 0.0f, nullptr) != PCT_OK) {
+                pct_cloud_destroy(bigger);
+                check(PCT_ERR_HIP, "pct_cloud_ring_index");
+            }
             pct_cloud_destroy(cloud_);
-            cloud_ = nullptr;
-            capacity_ = n + n / 2;
-            check(pct_cloud_create(capacity_, &cloud_), "pct_cloud_create");
+            cloud_ = bigger;
+            capacity_ = cap;
         }
         check(pct_cloud_upload_aos(cloud_, points, n, stride_bytes), "pct_cloud_upload_aos");
         cloud_empty_ = (n == 0);
-        if (build_index && n > 0) check(pct_cloud_build_grid(cloud_, 0.0f), "pct_cloud_build_grid");
+        if (build_index && n > 0 && !rolling_) check(pct_cloud_build_grid(cloud_, 0.0f), "pct_cloud_build_grid");
+    }
+    // rolling map with the in-place index (config C5): call once before the first appendInput; appends then update the index
+    // instead of dropping it, and every query below searches it
+    void enableRollingIndex(float cell_size = 0.0f, const float *extent = nullptr)
+    {
+        check(pct_cloud_ring_index(cloud_, cell_size, extent), "pct_cloud_ring_index");
+        rolling_ = true;
     }
     // rolling map (config C5): append the newest sensor frame, evicting the oldest points
     void appendInput(const void *points, int64_t n, int64_t stride_bytes = 16)
@@ -107,6 +120,19 @@ public:
               "pct_bezier_check");
         if (first_hit_sample) *first_hit_sample = fh;
         if (samples) *samples = ns;
+        return fh >= 0;
+    }
+
+    // SURVEY 3.3 (config C5's build extension): the same threshold test on the raw control points of the committed trajectory
+    // (control point j of segment i = poly_coeff[i][d*(n+1)+j] * T_i, the point traj_optimizer.cpp:624-648 keeps inside sphere i)
+    bool checkControlPoints(const double *poly_coeff, int64_t row_stride, const double *seg_time, const int32_t *orders,
+                            int32_t segment_num, double t_now, int64_t *first_hit_point = nullptr, int64_t *points = nullptr)
+    {
+        pct_bezier_traj tr{ poly_coeff, row_stride, seg_time, orders, segment_num };
+        int64_t fh = -1, nc = 0;
+        check(pct_ctrl_points_check(cloud_, &tr, &prm_, t_now, &fh, &nc, 0, nullptr, nullptr, nullptr, nullptr), "pct_ctrl_points_check");
+        if (first_hit_point) *first_hit_point = fh;
+        if (points) *points = nc;
         return fh >= 0;
     }
 
@@ -156,6 +182,7 @@ private:
     pct_cloud *cloud_ = nullptr;
     int64_t capacity_ = 0;
     bool cloud_empty_ = true;
+    bool rolling_ = false;
     double safety_margin_ = 0.0;
     pct_inflate_params prm_{ { 0, 0, 0 }, 0.0, 0.0, 0.0 };
 };

@@ -74,5 +74,16 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
         subprocess.run(cmd, check=True)
 
 
+    lat_src = os.path.join(ROOT, "examples", "latency_bench.cpp")
+    lat_bin = os.path.join(LIB, "latency_bench")
+    if os.path.exists(lat_src) and os.path.exists(KDTREE_SO) and (force or _stale(lat_bin, [lat_src, KDTREE_SO] + hdrs + [os.path.join(ROOT, "include", "pct_obstacle_map.hpp")])):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", lat_bin, lat_src,
+               "-L" + LIB, "-lkdtree", "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
+               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+
+
 if __name__ == "__main__":
     build_all(force=True, verbose=True)

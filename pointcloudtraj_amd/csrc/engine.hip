@@ -107,6 +107,8 @@ struct pct_cloud {
     ExpressOut *h_xout = nullptr, *d_xout = nullptr;
     double *h_xin = nullptr, *d_xin = nullptr, *h_xr = nullptr, *d_xr = nullptr;
     uint32_t *h_xids = nullptr, *d_xids = nullptr;
+    uint32_t *h_xseq = nullptr, *d_xseq = nullptr, *d_xcounter = nullptr;     // completion word of the express launches (kernels.hpp ExpressSignal)
+    uint32_t xseq = 0;
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
     double *h_aux = nullptr, *d_aux = nullptr;
     ExpandOut *h_eout = nullptr, *d_eout = nullptr;
@@ -212,6 +214,34 @@ struct pct_plan {
 };
 
 namespace {
+
+bool poll_results()
+{
+    static const bool v = [] { const char *e = std::getenv("PCT_POLL_RESULTS"); return e ? std::atoi(e) != 0 : true; }();
+    return v;
+}
+
+// completion word for the next express launch on this cloud (seq = nullptr when polling is off: express_wait then synchronises)
+ExpressSignal next_signal(pct_cloud *c)
+{
+    ++c->xseq;
+    return ExpressSignal{ c->d_xcounter, poll_results() ? c->d_xseq : nullptr, c->xseq };
+}
+
+// wait for the express launch that carried next_signal(): spin on the host-mapped word its last block stores (a stream
+// synchronise costs ~20 us of host time more), falling back to the stream after ~2 s of spinning
+int express_wait(pct_cloud *c)
+{
+    if (poll_results()) {
+        const volatile uint32_t *seq = c->h_xseq;
+        for (long spins = 0; spins < 200000000l; spins++) {
+            if (*seq == c->xseq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return PCT_OK; }
+            __builtin_ia32_pause();
+        }
+    }
+    HIPCHK(hipStreamSynchronize(g_stream));
+    return PCT_OK;
+}
 
 int require_init()
 {
@@ -780,6 +810,9 @@ static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out
     if (!s) s = mapped_alloc(&c->h_xin, &c->d_xin, 3 * kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xr, &c->d_xr, kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xids, &c->d_xids, kExpressIdsCap);
+    if (!s) s = mapped_alloc(&c->h_xseq, &c->d_xseq, 16);
+    if (!s) s = dev_alloc(&c->d_xcounter, 16);
+    if (!s) { *c->h_xseq = 0; if (hipMemset(c->d_xcounter, 0, 16 * sizeof(uint32_t)) != hipSuccess) s = fail(PCT_ERR_HIP, "hipMemset failed"); }
     if (s) {
         pct_cloud_destroy(c);
         return PCT_ERR_ALLOC;
@@ -818,6 +851,8 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xin) (void)hipHostFree(c->h_xin);
     if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
+    if (c->h_xseq) (void)hipHostFree(c->h_xseq);
+    dev_free(c->d_xcounter);
     if (c->h_aux) (void)hipHostFree(c->h_aux);
     if (c->h_eout) (void)hipHostFree(c->h_eout);
     if (c->h_bpos) (void)hipHostFree(c->h_bpos);
@@ -1129,9 +1164,9 @@ int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_
         // small batch on the rolling map: one launch, a block per query, arguments/results in mapped memory
         for (int64_t i = 0; i < 3 * Q; i++) c->h_xin[i] = (double)q[i];
         ring_batch_kernel<false><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), InflateParams{}, nullptr, c->d_xin, (double)INFINITY, (uint32_t)c->index_base,
-                                                               nullptr, nullptr, nullptr, c->d_xout);
+                                                               nullptr, nullptr, nullptr, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
         return PCT_OK;
     }
@@ -1139,9 +1174,9 @@ int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_
         // small batch on an indexed cloud: one launch, a block per query, arguments/results in mapped memory
         for (int64_t i = 0; i < 3 * Q; i++) c->h_xin[i] = (double)q[i];
         inflate_block_kernel<false><<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, InflateParams{}, c->d_xin, (double)INFINITY,
-                                                                   (uint32_t)c->index_base, c->d_xout);
+                                                                   (uint32_t)c->index_base, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
         return PCT_OK;
     }
@@ -1171,16 +1206,16 @@ int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, do
     }
     if (Q > 1 && Q <= kExpressMaxQ && c->count <= kSmallNNMax) {   // express batch: a block per query, everything in mapped memory
         std::memcpy(c->h_xin, q, sizeof(double) * 3 * Q);
-        nn_small_batch_kernel<<<(int)Q, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_xin, (uint32_t)c->index_base, c->d_xout);
+        nn_small_batch_kernel<<<(int)Q, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_xin, (uint32_t)c->index_base, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         for (int64_t i = 0; i < Q; i++) { idx[i] = c->h_xout[i].idx; d2[i] = c->h_xout[i].d2; }
         return PCT_OK;
     }
     if (Q == 1 && c->count <= kSmallNNMax) {   // express: one one-block launch, query by value, result in mapped memory
-        nn_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], (uint32_t)c->index_base, c->d_xout);
+        nn_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], (uint32_t)c->index_base, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         idx[0] = c->h_xout[0].idx;
         d2[0] = c->h_xout[0].d2;
         return PCT_OK;
@@ -1272,9 +1307,9 @@ int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *
     if (c->count == 0) return PCT_OK;
     if (c->count <= 4 * kSmallNNMax && c->count <= (int64_t)kExpressIdsCap) {   // express: one launch, ids in mapped memory
         radius_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], r * r, (uint32_t)c->index_base,
-                                                       c->d_xids, kExpressIdsCap, c->d_xout);
+                                                       c->d_xids, kExpressIdsCap, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         const int64_t total = c->h_xout[0].count, got = std::min<int64_t>(total, cap);
         std::copy(c->h_xids, c->h_xids + std::min<int64_t>(got, kExpressIdsCap), idx_out);
         std::sort(idx_out, idx_out + got);
@@ -1354,9 +1389,9 @@ int pct_radius_indices_batch_q64(pct_cloud *c, const double *q, const double *r,
     std::memcpy(c->h_xin, q, sizeof(double) * 3 * K);
     std::memcpy(c->h_xr, r, sizeof(double) * K);
     radius_small_batch_kernel<<<(int)K, 256, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, c->d_xin, c->d_xr, (uint32_t)c->index_base,
-                                                            c->d_xids, cap, c->d_xout);
+                                                            c->d_xids, cap, c->d_xout, next_signal(c));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g_stream));
+    PCTCHK(express_wait(c));
     for (int64_t k = 0; k < K; k++) {
         counts_out[k] = c->h_xout[k].count;
         const int64_t got = std::min<int64_t>(counts_out[k], cap);
@@ -1376,9 +1411,9 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
         if (Q <= kExpressMaxQ) {
             std::memcpy(c->h_xin, pts, sizeof(double) * 3 * Q);
             ring_batch_kernel<true><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), to_dev(p), nullptr, c->d_xin, stop_d2, (uint32_t)c->index_base, nullptr, nullptr,
-                                                                  nullptr, c->d_xout);
+                                                                  nullptr, c->d_xout, next_signal(c));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(g_stream));
+            PCTCHK(express_wait(c));
             for (int64_t i = 0; i < Q; i++) {
                 radius[i] = c->h_xout[i].radius;
                 if (idx) idx[i] = c->h_xout[i].idx;
@@ -1389,7 +1424,7 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
         PCTCHK(pct_cloud_reserve_queries(c, Q));
         HIPCHK(hipMemcpyAsync(c->d_pts64, pts, sizeof(double) * 3 * Q, hipMemcpyHostToDevice, g_stream));
         ring_batch_kernel<true><<<(int)Q, 256, 0, g_stream>>>(ring_view(c), to_dev(p), nullptr, c->d_pts64, stop_d2, (uint32_t)c->index_base, c->d_idx, c->d_d2,
-                                                              c->d_radius, nullptr);
+                                                              c->d_radius, nullptr, ExpressSignal{});
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(radius, c->d_radius, sizeof(double) * Q, hipMemcpyDeviceToHost, g_stream));
         if (idx) HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
@@ -1402,9 +1437,9 @@ int pct_inflate_batch(pct_cloud *c, const pct_inflate_params *p, const double *p
         // idx / d2 not wanted: the search may stop once everything unseen is beyond max_radius + search_margin
         const double reach = p->max_radius + p->search_margin;
         const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
-        inflate_block_kernel<true><<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, stop_d2, (uint32_t)c->index_base, c->d_xout);
+        inflate_block_kernel<true><<<(int)Q, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, stop_d2, (uint32_t)c->index_base, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(g_stream));
+        PCTCHK(express_wait(c));
         for (int64_t i = 0; i < Q; i++) {
             radius[i] = c->h_xout[i].radius;
             if (idx) idx[i] = c->h_xout[i].idx;
@@ -1457,9 +1492,9 @@ int pct_rrt_expand_batch(pct_cloud *nodes, pct_cloud *obstacles, const pct_infla
     const double reach = p->max_radius + p->search_margin;       // only the radius is wanted: stop once everything unseen is beyond it
     rrt_expand_kernel<<<(int)K, 256, 0, g_stream>>>(nodes->x, nodes->y, nodes->z, (uint32_t)nodes->count, nodes->d_aux, nodes->d_xin,
                                                     obstacles->G, obstacles->sorted, obstacles->cell_start, obstacles->C,
-                                                    obstacles->count == 0 ? 1 : 0, to_dev(p), reach * reach, nodes->d_xids, cap, nodes->d_eout);
+                                                    obstacles->count == 0 ? 1 : 0, to_dev(p), reach * reach, nodes->d_xids, cap, nodes->d_eout, next_signal(nodes));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g_stream));
+    PCTCHK(express_wait(nodes));
     for (int64_t k = 0; k < K; k++) {
         const ExpandOut &e = nodes->h_eout[k];
         out[k].center[0] = e.cx; out[k].center[1] = e.cy; out[k].center[2] = e.cz;
@@ -1528,15 +1563,16 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
                 const double stop_d2 = (idx || d2) ? (double)INFINITY : reach * reach;
                 bezier_block_kernel<<<(int)m, 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, c->C, to_dev(p), c->d_xin, (int)traj->row_stride,
                                                                    c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg, c->d_xin + ncoef + traj->nseg,
-                                                                   stop_d2, (uint32_t)c->index_base, c->d_xout, c->d_bpos);
+                                                                   stop_d2, (uint32_t)c->index_base, c->d_xout, c->d_bpos, next_signal(c));
                 HIPCHK(hipGetLastError());
+                PCTCHK(express_wait(c));
             } else {                                      // un-indexed (rolling) cloud: evaluate, then the brute-force inflation; still no copies
                 PCTCHK(pct_cloud_reserve_queries(c, m));
                 bezier_eval_kernel<<<ceil_div(m, 128), 128, 0, g_stream>>>(c->d_xin, (int)traj->row_stride, c->d_xin + ncoef, c->d_xids, c->d_xids + traj->nseg,
                                                                            c->d_xin + ncoef + traj->nseg, (int)m, c->d_pts64, c->d_bpos);
                 PCTCHK(inflate_dev(c, p, m, g_stream, c->d_pts64, c->d_xout));
+                HIPCHK(hipStreamSynchronize(g_stream));
             }
-            HIPCHK(hipStreamSynchronize(g_stream));
         }
         if (fits) {
             int64_t fh = -1;

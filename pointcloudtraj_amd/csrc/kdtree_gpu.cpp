@@ -306,13 +306,16 @@ struct kdres *kd_nearest_range3f(struct kdtree *t, float x, float y, float z, fl
     return kd_nearest_range(t, w, range);
 }
 
-// kdtree.c:613-639
+// kdtree.c:613-639.  A NULL result set (kd_nearest* on an empty tree, or a device failure reported through pct_last_error)
+// reads as an empty, exhausted set here; the reference dereferences it (kd_res_free(NULL) and kd_res_next on an exhausted
+// cursor crash there) -- no correct caller can tell the difference.
 void kd_res_free(struct kdres *r) { delete r; }
-int kd_res_size(struct kdres *r) { return r->size; }
-void kd_res_rewind(struct kdres *r) { r->cursor = 0; }
-int kd_res_end(struct kdres *r) { return r->cursor >= r->items.size(); }
+int kd_res_size(struct kdres *r) { return r ? r->size : 0; }
+void kd_res_rewind(struct kdres *r) { if (r) r->cursor = 0; }
+int kd_res_end(struct kdres *r) { return !r || r->cursor >= r->items.size(); }
 int kd_res_next(struct kdres *r)
 {
+    if (!r) return 0;
     if (r->cursor < r->items.size()) r->cursor++;
     return r->cursor < r->items.size();
 }
@@ -320,14 +323,14 @@ int kd_res_next(struct kdres *r)
 // kdtree.c:641-664
 void *kd_res_item(struct kdres *r, double *pos)
 {
-    if (r->cursor >= r->items.size()) return nullptr;
+    if (!r || r->cursor >= r->items.size()) return nullptr;
     const int32_t n = r->items[r->cursor];
     if (pos) std::memcpy(pos, &r->tree->pos[3 * (size_t)n], 3 * sizeof(double));
     return r->tree->data[n];
 }
 void *kd_res_itemf(struct kdres *r, float *pos)
 {
-    if (r->cursor >= r->items.size()) return nullptr;
+    if (!r || r->cursor >= r->items.size()) return nullptr;
     const int32_t n = r->items[r->cursor];
     if (pos) for (int i = 0; i < 3; i++) pos[i] = (float)r->tree->pos[3 * (size_t)n + i];
     return r->tree->data[n];
@@ -335,7 +338,7 @@ void *kd_res_itemf(struct kdres *r, float *pos)
 // kdtree.c:666-684: tests the pointee, never returns the payload -- kept as is
 void *kd_res_item3(struct kdres *r, double *x, double *y, double *z)
 {
-    if (r->cursor < r->items.size()) {
+    if (r && r->cursor < r->items.size()) {
         const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
         if (*x) *x = p[0];
         if (*y) *y = p[1];
@@ -345,7 +348,7 @@ void *kd_res_item3(struct kdres *r, double *x, double *y, double *z)
 }
 void *kd_res_item3f(struct kdres *r, float *x, float *y, float *z)
 {
-    if (r->cursor < r->items.size()) {
+    if (r && r->cursor < r->items.size()) {
         const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
         if (*x) *x = (float)p[0];
         if (*y) *y = (float)p[1];

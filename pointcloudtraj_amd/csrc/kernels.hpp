@@ -1792,10 +1792,38 @@ __global__ __launch_bounds__(256) void count_grid_kernel(GridDesc G, const float
 // =====================================================================================
 struct ExpressOut { double d2; double radius; uint32_t idx; uint32_t count; };
 
+// Completion word of an express launch.  hipStreamSynchronize costs ~20 us of host time however short the kernel
+// (profiles/r01_corridor_rocprof_summary.txt); here the kernel itself tells the host it is done: the thread that wrote a block's
+// results fences them to system scope and takes a ticket, the block holding the last ticket stores `value` (release, system
+// scope) into a word of host-mapped memory the host spins on.  seq == nullptr: no signalling (the caller synchronises).
+struct ExpressSignal { uint32_t *counter; uint32_t *seq; uint32_t value; };
+
+// called by the ONE thread that stored the block's host-visible results, after the stores
+__device__ __forceinline__ void express_done(const ExpressSignal &S)
+{
+    if (!S.seq) return;
+    __threadfence_system();
+    bool last = gridDim.x == 1;
+    if (!last) {
+        last = atomicAdd(S.counter, 1u) == gridDim.x - 1;
+        if (last) { atomicExch(S.counter, 0u); __threadfence_system(); }
+    }
+    if (last) __hip_atomic_store(S.seq, S.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the same for kernels in which every thread stores host-visible data: all fence, the block meets, thread 0 signals
+__device__ __forceinline__ void express_done_block(const ExpressSignal &S)
+{
+    if (!S.seq) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) express_done(S);
+}
+
 // one block, exact fp64 brute force over a small cloud (the RRT* node set of the kd_* drop-in)
 __global__ __launch_bounds__(1024) void nn_small_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                         const float *__restrict__ z, uint32_t n, double qx, double qy, double qz,
-                                                        uint32_t index_base, ExpressOut *__restrict__ out)
+                                                        uint32_t index_base, ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     double bd = __builtin_huge_val();
     uint32_t bi = kNoIndex;
@@ -1813,6 +1841,7 @@ __global__ __launch_bounds__(1024) void nn_small_kernel(const float *__restrict_
             if (better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
         out->d2 = bd;
         out->idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        express_done(sig);
     }
 }
 
@@ -1820,7 +1849,7 @@ __global__ __launch_bounds__(1024) void nn_small_kernel(const float *__restrict_
 __global__ __launch_bounds__(1024) void radius_small_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                             const float *__restrict__ z, uint32_t n, double qx, double qy, double qz,
                                                             double r2, uint32_t index_base, uint32_t *__restrict__ ids, uint32_t cap,
-                                                            ExpressOut *__restrict__ out)
+                                                            ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
@@ -1832,6 +1861,7 @@ __global__ __launch_bounds__(1024) void radius_small_kernel(const float *__restr
         }
     __syncthreads();
     if (threadIdx.x == 0) out->count = s_n;
+    express_done_block(sig);
 }
 
 // =====================================================================================
@@ -1841,7 +1871,7 @@ __global__ __launch_bounds__(1024) void radius_small_kernel(const float *__restr
 __global__ __launch_bounds__(256) void nn_small_batch_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                              const float *__restrict__ z, uint32_t n,
                                                              const double *__restrict__ q, uint32_t index_base,
-                                                             ExpressOut *__restrict__ out)
+                                                             ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -1860,6 +1890,7 @@ __global__ __launch_bounds__(256) void nn_small_batch_kernel(const float *__rest
             if (better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
         out[blockIdx.x].d2 = bd;
         out[blockIdx.x].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        express_done(sig);
     }
 }
 
@@ -1868,7 +1899,7 @@ __global__ __launch_bounds__(256) void radius_small_batch_kernel(const float *__
                                                                  const float *__restrict__ z, uint32_t n,
                                                                  const double *__restrict__ q, const double *__restrict__ r,
                                                                  uint32_t index_base, uint32_t *__restrict__ ids,
-                                                                 uint32_t cap_per_query, ExpressOut *__restrict__ out)
+                                                                 uint32_t cap_per_query, ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     __shared__ uint32_t s_n;
     if (threadIdx.x == 0) s_n = 0;
@@ -1882,6 +1913,7 @@ __global__ __launch_bounds__(256) void radius_small_batch_kernel(const float *__
         }
     __syncthreads();
     if (threadIdx.x == 0) out[blockIdx.x].count = s_n;
+    express_done_block(sig);
 }
 
 struct InflateParams { double sx, sy, sz, sample_range, search_margin, max_radius; };
@@ -2008,7 +2040,7 @@ template <bool INFLATE>
 __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const float4 *__restrict__ pts0,
                                                             const uint32_t *__restrict__ cs0, CoarseLevels C, InflateParams P,
                                                             const double *__restrict__ qpts, double stop_d2, uint32_t index_base,
-                                                            ExpressOut *__restrict__ out)
+                                                            ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -2017,7 +2049,7 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const f
     if (INFLATE) {
         const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
         if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {      // corridor_finder.cpp:115-116
-            if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
+            if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); express_done(sig); }
             return;
         }
     }
@@ -2031,6 +2063,7 @@ __global__ __launch_bounds__(256) void inflate_block_kernel(GridDesc G0, const f
         }
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
+        express_done(sig);
     }
 }
 
@@ -2050,7 +2083,8 @@ __global__ __launch_bounds__(256) void rrt_expand_kernel(const float *__restrict
                                                          const double *__restrict__ node_aux, const double *__restrict__ samples,
                                                          GridDesc G0, const float4 *__restrict__ pts0, const uint32_t *__restrict__ cs0,
                                                          CoarseLevels C, int obstacles_empty, InflateParams P, double stop_d2,
-                                                         uint32_t *__restrict__ ids, uint32_t cap_per_query, ExpandOut *__restrict__ out)
+                                                         uint32_t *__restrict__ ids, uint32_t cap_per_query, ExpandOut *__restrict__ out,
+                                                         ExpressSignal sig)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -2113,6 +2147,7 @@ __global__ __launch_bounds__(256) void rrt_expand_kernel(const float *__restrict
         out[slot].near_idx = near;
         out[slot].count = s_n;
     }
+    express_done_block(sig);
 }
 
 constexpr int kMaxBezierOrder = 12;
@@ -2188,7 +2223,7 @@ __global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const fl
                                                            const double *__restrict__ seg_time, const uint32_t *__restrict__ orders,
                                                            const uint32_t *__restrict__ sample_seg, const double *__restrict__ sample_t,
                                                            double stop_d2, uint32_t index_base, ExpressOut *__restrict__ out,
-                                                           double *__restrict__ pos_out)
+                                                           double *__restrict__ pos_out, ExpressSignal sig)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -2210,13 +2245,14 @@ __global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const fl
         double acc = 0.0;
         for (int j = 0; j < m; j++) acc += s_term[threadIdx.x * m + j];
         s_pos[threadIdx.x] = acc * T;
-        pos_out[3 * slot + threadIdx.x] = acc * T;
     }
     __syncthreads();
     const double px = s_pos[0], py = s_pos[1], pz = s_pos[2];
+    // every host-visible store of the block comes from thread 0, so one thread fences and signals
+    if (threadIdx.x == 0) { pos_out[3 * slot] = px; pos_out[3 * slot + 1] = py; pos_out[3 * slot + 2] = pz; }
     const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
     if (sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {          // corridor_finder.cpp:115-116
-        if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); }
+        if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); express_done(sig); }
         return;
     }
     double bd;
@@ -2227,6 +2263,7 @@ __global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const fl
         out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
+        express_done(sig);
     }
 }
 

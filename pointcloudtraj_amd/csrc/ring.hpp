@@ -393,7 +393,7 @@ template <bool INFLATE>
 __global__ __launch_bounds__(256) void ring_batch_kernel(RingView V, InflateParams P, const float *__restrict__ qf, const double *__restrict__ q64,
                                                          double stop_d2, uint32_t index_base, uint32_t *__restrict__ out_idx,
                                                          double *__restrict__ out_d2, double *__restrict__ out_radius,
-                                                         ExpressOut *__restrict__ out_rec)
+                                                         ExpressOut *__restrict__ out_rec, ExpressSignal sig)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void ring_batch_kernel(RingView V, InflatePara
         if (out_d2) out_d2[slot] = bd;
         if (out_radius) out_radius[slot] = radius;
         if (out_rec) { out_rec[slot].idx = gi; out_rec[slot].d2 = bd; out_rec[slot].radius = radius; out_rec[slot].count = 0; }
+        express_done(sig);
     }
 }
 

@@ -143,6 +143,13 @@ def test_bezier_golden(E, grid):
         same = np.all(r["pos"].astype(np.float32) == want_pos.astype(np.float32), axis=1)
         assert same.mean() > 0.9
         assert np.array_equal(r["d2"][same], g[f"case{i}_d2"][same])
+        assert np.array_equal(r["idx"][same].astype(np.int64), np.where(g[f"case{i}_idx"][same] < 0, np.int64(E.NO_INDEX), g[f"case{i}_idx"][same].astype(np.int64)))
+        # the collision decision is pinned on every sample: where the fp32-narrowed position is bit-identical the radius is
+        # too; where device pow and libm pow differ in the last ulp the radius must be far enough from zero (1e-6) that the
+        # difference cannot flip it -- so first_hit can never sit on, or behind, a sample decided on unpinned input
+        want_rad = g[f"case{i}_radius"]
+        assert np.array_equal(r["radius"][same], want_rad[same])
+        assert np.all(np.abs(want_rad[~same]) > 1e-6) and np.array_equal(r["radius"] < 0, want_rad < 0)
     c.close()
 
 
