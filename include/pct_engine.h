@@ -202,6 +202,9 @@ int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const f
  * elsewhere -- so the second reduction returns the lowest global index among the ranks that tie.  Device pointers, async on
  * `stream`; global indices must be < 2^31 - 1. */
 int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const uint32_t *d_idx_local, int32_t *d_cand, int64_t Q, void *stream);
+/* behind the second reduction: merged int32 candidates -> u32 indices (INT32_MAX -> PCT_NO_INDEX).  include/pct_shard.h wraps the
+ * whole exchange step (these two kernels + the RCCL calls) for C / C++ callers. */
+int pct_merge_finish_dev(const int32_t *d_cand, uint32_t *d_idx, int64_t Q, void *stream);
 /* make sure workspaces for batches up to Q exist (call before capturing a graph) */
 int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q);
 

@@ -18,6 +18,8 @@ ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
 KDTREE_SO = os.path.join(LIB, "libkdtree.so")
 DEMO_BIN = os.path.join(LIB, "seam_demo")
 CORRIDOR_SO = os.path.join(LIB, "libpct_corridor.so")
+SHARD_SO = os.path.join(LIB, "libpct_shard.so")
+SHARD_CLIENT = os.path.join(LIB, "shard_client")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 COMMON = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -74,6 +76,24 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
         subprocess.run(cmd, check=True)
 
 
+    # multi-GPU exchange step: host-only C++ over libpct_engine.so's C ABI + RCCL (ncclAllReduce over xGMI)
+    shard_src = os.path.join(CSRC, "shard.cpp")
+    shard_hdr = os.path.join(ROOT, "include", "pct_shard.h")
+    if os.path.exists(shard_src) and (force or _stale(SHARD_SO, [shard_src, shard_hdr, ENGINE_SO] + hdrs)):
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", SHARD_SO, shard_src,
+               "-L" + LIB, "-lpct_engine", "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-soname,libpct_shard.so"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    client_src = os.path.join(ROOT, "examples", "shard_client.cpp")
+    if os.path.exists(client_src) and os.path.exists(SHARD_SO) and (force or _stale(SHARD_CLIENT, [client_src, SHARD_SO, shard_hdr] + hdrs)):
+        # the link line a planner node adds: -lpct_shard -lpct_engine (RCCL and the HIP runtime come in through libpct_shard.so)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", SHARD_CLIENT, client_src,
+               "-L" + LIB, "-lpct_shard", "-lpct_engine", "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
+               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     lat_src = os.path.join(ROOT, "examples", "latency_bench.cpp")
     lat_bin = os.path.join(LIB, "latency_bench")
     if os.path.exists(lat_src) and os.path.exists(KDTREE_SO) and (force or _stale(lat_bin, [lat_src, KDTREE_SO] + hdrs + [os.path.join(ROOT, "include", "pct_obstacle_map.hpp")])):

@@ -1723,6 +1723,16 @@ int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const 
     return PCT_OK;
 }
 
+int pct_merge_finish_dev(const int32_t *d_cand, uint32_t *d_idx, int64_t Q, void *stream)
+{
+    if (Q < 0 || (Q > 0 && (!d_cand || !d_idx))) return fail(PCT_ERR_INVALID, "bad merge_finish arguments");
+    if (Q == 0) return PCT_OK;
+    PCTCHK(require_init());
+    merge_finish_kernel<<<ceil_div(Q, 256), 256, 0, (hipStream_t)stream>>>(d_cand, d_idx, (uint32_t)Q);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
 int pct_set_timing(pct_cloud *c, int level)
 {
     if (!c || level < 0 || level > 2) return fail(PCT_ERR_INVALID, "timing level must be 0, 1 or 2");

@@ -549,6 +549,13 @@ __global__ __launch_bounds__(256) void merge_mask_kernel(const double *__restric
 
 // one 256-thread block per query folds the per-block partials (loads issued back to back,
 // compared afterwards); adds the shard's index base
+// behind the second reduction: the merged int32 candidates back to the engine's index convention (INT32_MAX = no shard holds a point)
+__global__ __launch_bounds__(256) void merge_finish_kernel(const int32_t *__restrict__ cand, uint32_t *__restrict__ idx, uint32_t Q)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q) idx[i] = cand[i] == 0x7FFFFFFF ? kNoIndex : (uint32_t)cand[i];
+}
+
 __global__ __launch_bounds__(256) void nn_reduce_partials_kernel(const double *__restrict__ part_d2,
                                                                  const uint32_t *__restrict__ part_idx, int nparts,
                                                                  uint32_t index_base, uint32_t *__restrict__ out_idx,

@@ -76,12 +76,31 @@ def test_corridor_exports_every_declared_symbol(built):
     assert not missing, missing
 
 
+def test_shard_library_exports_every_declared_symbol_and_links_rccl(built):
+    """libpct_shard.so (include/pct_shard.h): the multi-GPU exchange step for C / C++ callers; it must resolve RCCL's
+    ncclAllReduce itself (DT_NEEDED librccl) and the example client must have linked against it"""
+    import ctypes as C2
+    import subprocess
+    from pointcloudtraj_amd import engine as E
+    names = declared("pct_shard.h", "pct_shard_")
+    assert len(names) >= 11
+    E._preload_hip_runtime()
+    L = C2.CDLL(built.SHARD_SO)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    needed = subprocess.run(["readelf", "-d", built.SHARD_SO], capture_output=True, text=True).stdout
+    assert "librccl.so" in needed and "libpct_engine.so" in needed
+    und = subprocess.run(["nm", "-D", "--undefined-only", built.SHARD_SO], capture_output=True, text=True).stdout
+    assert "ncclAllReduce" in und and "ncclCommInitRank" in und and "pct_merge_mask_dev" in und
+    assert os.path.exists(built.SHARD_CLIENT)
+
+
 def test_public_headers_are_plain_c99_and_cxx17():
     """The drop-in boundary is a C ABI: every include/*.h must compile as C99 on its own (no C++, no torch/HIP types), and the
     two C++ mirrors as C++17 without any GPU toolchain header."""
     import subprocess
     inc = os.path.join(ROOT, "include")
-    for h in ("pct_engine.h", "pct_voxel.h", "pct_traj.h", "pct_corridor.h", "kdtree/kdtree.h", "kdtree/kdtree_ext.h"):
+    for h in ("pct_engine.h", "pct_shard.h", "pct_voxel.h", "pct_traj.h", "pct_corridor.h", "kdtree/kdtree.h", "kdtree/kdtree_ext.h"):
         r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I" + inc, "-x", "c", "-fsyntax-only", "-"],
                            input=f'#include "{h}"\n', text=True, capture_output=True)
         assert r.returncode == 0, h + ":\n" + r.stderr

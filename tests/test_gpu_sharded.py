@@ -115,3 +115,13 @@ def test_bench_two_ranks_on_one_card():
     assert abs(d["config"]["query_shard_evaluations_per_s"] - 2 * d["value"]) < 1e-6 * d["value"]
     assert d["one_gpu_whole_cloud"]["same_answers_as_sharded"] is True
     assert d["c4_q4096"]["brute_force_ms_per_batch"] > 0
+
+
+def test_cpp_shard_client_over_rccl():
+    """examples/shard_client.cpp through include/pct_shard.h: ncclCommInitRank, the per-shard kernels, ncclAllReduce(min) x 2 and the
+    two merge kernels, all from a plain C++ process.  This box has one card and RCCL refuses two ranks on one device, so the
+    communicator has ONE rank here (the collectives still run); examples/run_shard_client.sh 8 is the 8-GPU form."""
+    import subprocess
+    r = subprocess.run(["bash", os.path.join(ROOT, "examples", "run_shard_client.sh"), "1", "3000000", "2048"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
