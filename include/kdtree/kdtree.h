@@ -18,9 +18,10 @@
  *     an empty tree gives a valid empty set (:537-559)
  *   - result items alias live tree nodes: a set is invalidated by kd_clear/kd_free
  *   - kd_res_item3/kd_res_item3f test the pointee, not the pointer, and return NULL (:666-684)
+ *   - kd_nearest* on exact distance ties: the node the reference's own walk returns -- the root if it is
+ *     among the tied nodes (it is the initial guess and only a strictly smaller distance displaces it,
+ *     :432-436), otherwise the tied node reached first by "nearer subtree, node, farther subtree" (:345-402)
  * Documented differences:
- *   - exact distance ties: the reference's winner depends on tree shape; this library
- *     returns the LOWEST insertion index among fp64-equal minima
  *   - only k == 3 is served by the device path; kd_create(k != 3) returns NULL
  *   - every query needs a HIP device; there is no host fallback (queries return NULL and
  *     print a diagnostic when the device is missing)

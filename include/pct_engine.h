@@ -117,6 +117,9 @@ int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double 
 int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_t *idx, double *d2);
 /* same with fp64 query coordinates (kd_nearest's double positions); streaming kernel */
 int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2);
+/* the same, also reporting how many points attain the minimum: ties[i] >= 1 where counted (single queries against clouds of up
+ * to 16384 points -- the RRT* node sets of the kd_* drop-in), 0 = not counted on the path taken.  ties may be NULL. */
+int pct_nn_batch_q64_ties(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2, uint32_t *ties);
 /* count[Q] = #points with d2 <= r*r */
 int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t Q, uint32_t *count);
 int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const float *r, int64_t Q, uint32_t *count);
@@ -124,6 +127,9 @@ int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const fl
  * ascending index order; returns the count through *n_out (may exceed cap; only cap written). */
 int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
 int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+/* the same with the SQUARED radius given exactly (d2 <= r2): with r2 = the d2 a nearest-neighbour query returned it lists every
+ * point tied at the minimum */
+int pct_radius_indices_r2_q64(pct_cloud *c, const double q[3], double r2, uint32_t *idx_out, int64_t cap, int64_t *n_out);
 /* The same crop with everything its consumer builds from it: idx_out[cap], d2_out[cap] (fp64, kdtree.c arithmetic) and
  * xyz_out[cap*3] (the cropped cloud = pcl::PointCloud(cloud, indices)); any of the three may be NULL.  Order: ascending
  * index, or -- sort_by_distance != 0 -- nearest first with ties in ascending index, the order pcl's radiusSearch returns

@@ -1197,8 +1197,14 @@ int pct_nn_batch(pct_cloud *c, const float *q, int64_t Q, uint32_t *idx, double 
 
 int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2)
 {
+    return pct_nn_batch_q64_ties(c, q, Q, idx, d2, nullptr);
+}
+
+int pct_nn_batch_q64_ties(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, double *d2, uint32_t *ties)
+{
     if (!c || Q < 0 || (Q > 0 && (!q || !idx || !d2))) return fail(PCT_ERR_INVALID, "bad nn_batch_q64 arguments");
     if (Q == 0) return PCT_OK;
+    if (ties) for (int64_t i = 0; i < Q; i++) ties[i] = 0;        // 0 = not counted on this path
     PCTCHK(pct_cloud_reserve_queries(c, Q));
     if (c->count == 0) {
         for (int64_t i = 0; i < Q; i++) { idx[i] = PCT_NO_INDEX; d2[i] = INFINITY; }
@@ -1218,6 +1224,7 @@ int pct_nn_batch_q64(pct_cloud *c, const double *q, int64_t Q, uint32_t *idx, do
         PCTCHK(express_wait(c));
         idx[0] = c->h_xout[0].idx;
         d2[0] = c->h_xout[0].d2;
+        if (ties) ties[0] = c->h_xout[0].count;
         return PCT_OK;
     }
     // The fp32 filter is only valid when the query coordinates themselves are fp32 values
@@ -1259,7 +1266,7 @@ int pct_radius_count_batch(pct_cloud *c, const float *q, const float *r, int64_t
 }
 
 // order-preserving compaction of the points within r of q into c->crop_* (kernels.hpp section 1b)
-static int crop_device(pct_cloud *c, const double q[3], double r, int64_t *total_out)
+static int crop_device(pct_cloud *c, const double q[3], double rr, int64_t *total_out)
 {
     const uint32_t n = (uint32_t)c->count;
     const uint32_t ntiles = (n + kCropTile - 1) / kCropTile;
@@ -1277,7 +1284,6 @@ static int crop_device(pct_cloud *c, const double q[3], double r, int64_t *total
         PCTCHK(dev_alloc(&c->crop_x, cap)); PCTCHK(dev_alloc(&c->crop_y, cap)); PCTCHK(dev_alloc(&c->crop_z, cap));
         c->crop_cap = cap;
     }
-    const double rr = r * r;
     begin_timing(c, g_stream);
     HIPCHK(hipMemsetAsync(c->crop_tile + ntiles, 0, sizeof(uint32_t), g_stream));
     crop_count_kernel<<<(int)ntiles, 256, 0, g_stream>>>(c->x, c->y, c->z, n, q[0], q[1], q[2], rr, c->crop_tile);
@@ -1302,11 +1308,16 @@ int pct_radius_indices(pct_cloud *c, const float q[3], float r, uint32_t *idx_ou
 
 int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *idx_out, int64_t cap, int64_t *n_out)
 {
+    return pct_radius_indices_r2_q64(c, q, r * r, idx_out, cap, n_out);
+}
+
+int pct_radius_indices_r2_q64(pct_cloud *c, const double q[3], double r2, uint32_t *idx_out, int64_t cap, int64_t *n_out)
+{
     if (!c || !q || cap < 0 || (cap > 0 && !idx_out) || !n_out) return fail(PCT_ERR_INVALID, "bad radius_indices arguments");
     *n_out = 0;
     if (c->count == 0) return PCT_OK;
     if (c->count <= 4 * kSmallNNMax && c->count <= (int64_t)kExpressIdsCap) {   // express: one launch, ids in mapped memory
-        radius_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], r * r, (uint32_t)c->index_base,
+        radius_small_kernel<<<1, 1024, 0, g_stream>>>(c->x, c->y, c->z, (uint32_t)c->count, q[0], q[1], q[2], r2, (uint32_t)c->index_base,
                                                        c->d_xids, kExpressIdsCap, c->d_xout, next_signal(c));
         HIPCHK(hipGetLastError());
         PCTCHK(express_wait(c));
@@ -1317,7 +1328,7 @@ int pct_radius_indices_q64(pct_cloud *c, const double q[3], double r, uint32_t *
         return PCT_OK;
     }
     int64_t total = 0;
-    PCTCHK(crop_device(c, q, r, &total));                  // ascending index order, no host sort needed
+    PCTCHK(crop_device(c, q, r2, &total));                 // ascending index order, no host sort needed
     const int64_t got = std::min<int64_t>(total, cap);
     if (got > 0) {
         HIPCHK(hipMemcpyAsync(idx_out, c->crop_idx, sizeof(uint32_t) * got, hipMemcpyDeviceToHost, g_stream));
@@ -1335,7 +1346,7 @@ int pct_radius_crop(pct_cloud *c, const double q[3], double r, int sort_by_dista
     *n_out = 0;
     if (c->count == 0) return PCT_OK;
     int64_t total = 0;
-    PCTCHK(crop_device(c, q, r, &total));
+    PCTCHK(crop_device(c, q, r * r, &total));
     *n_out = total;
     const int64_t got = std::min<int64_t>(total, cap);
     if (got == 0) return PCT_OK;
@@ -1370,7 +1381,7 @@ int pct_cloud_crop_to(pct_cloud *src, const double q[3], double r, pct_cloud *ds
 {
     if (!src || !dst || !q || src == dst) return fail(PCT_ERR_INVALID, "bad crop_to arguments");
     int64_t total = 0;
-    if (src->count) PCTCHK(crop_device(src, q, r, &total));
+    if (src->count) PCTCHK(crop_device(src, q, r * r, &total));
     if (total > dst->cap) return fail(PCT_ERR_CAPACITY, "crop holds %lld points, destination capacity is %lld", (long long)total, (long long)dst->cap);
     return pct_cloud_upload_soa_dev(dst, src->crop_x, src->crop_y, src->crop_z, total);
 }

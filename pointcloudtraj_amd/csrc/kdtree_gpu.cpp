@@ -15,8 +15,9 @@
 //            810-828), and a hit behind a split plane with fabs(dx) == range is dropped
 //            (:283).  The host replays exactly that filter and order over the GPU's hit list.
 //
-// Deliberate differences (documented in include/kdtree/kdtree.h): lowest insertion index on
-// exact distance ties; k == 3 only; stored coordinates must be representable in fp32 (always
+// Exact distance ties in kd_nearest* resolve to the node the reference's own walk returns (reference_tie_winner below;
+// the batched kdx_* extensions and the obstacle-cloud engine keep "lowest index").
+// Deliberate differences (documented in include/kdtree/kdtree.h): k == 3 only; stored coordinates must be representable in fp32 (always
 // true for the *f entry points, which are the only ones the planner uses); no host fallback.
 #include <algorithm>
 #include <cmath>
@@ -153,6 +154,33 @@ kdres *build_range_result(kdtree *t, const double *q, double range, const uint32
     return r;
 }
 
+// The reference's winner among several nodes at exactly the minimum distance (kdtree.c:345-402, 432-436).  kd_nearest starts with the
+// root as its guess and replaces it only on a STRICTLY smaller distance, walking "nearer subtree, then the node, then the
+// farther subtree (if its box is strictly closer than the best so far)".  So: a tied root keeps the answer; otherwise the tied node
+// that this walk reaches first wins -- and pruning cannot hide it, because until a tied node has been seen the best distance is
+// larger than the minimum, which is at least the box distance of any subtree holding a tied node.  The walk position of a node
+// is its root path written as 0 = "into the nearer child", 2 = "into the farther child", closed by 1 = "the node itself".
+int32_t reference_tie_winner(const kdtree *t, const double *q, const uint32_t *tied, int64_t n)
+{
+    std::vector<uint8_t> best, cur;
+    int32_t win = NIL;
+    for (int64_t k = 0; k < n; k++) {
+        const int32_t id = (int32_t)tied[k];
+        if (id == 0) return 0;                                   // the root is the initial guess and is never displaced by an equal distance
+        cur.clear();
+        for (int32_t c = id, a = t->parent[id]; a != NIL; c = a, a = t->parent[a]) {
+            const int ax = t->axis[a];
+            const double dx = q[ax] - t->pos[3 * (size_t)a + ax];
+            const int32_t near_child = dx <= 0.0 ? t->lo[a] : t->hi[a];
+            cur.push_back(c == near_child ? 0 : 2);
+        }
+        std::reverse(cur.begin(), cur.end());
+        cur.push_back(1);
+        if (win == NIL || std::lexicographical_compare(cur.begin(), cur.end(), best.begin(), best.end())) { win = id; best = cur; }
+    }
+    return win;
+}
+
 }  // namespace
 
 extern "C" {
@@ -248,9 +276,17 @@ struct kdres *kd_nearest(struct kdtree *t, const double *q)
 {
     if (!t || t->count() == 0) return nullptr;
     if (sync_device(t)) return nullptr;
-    uint32_t idx = PCT_NO_INDEX;
+    uint32_t idx = PCT_NO_INDEX, ties = 0;
     double d2 = 0;
-    if (pct_nn_batch_q64(t->cloud, q, 1, &idx, &d2) != PCT_OK) { complain("kd_nearest"); return nullptr; }
+    if (pct_nn_batch_q64_ties(t->cloud, q, 1, &idx, &d2, &ties) != PCT_OK) { complain("kd_nearest"); return nullptr; }
+    if (ties != 1) {
+        // several nodes at exactly the minimum distance (ties > 1), or a path that does not count them (0: trees beyond 16384
+        // nodes): fetch the tied set and pick the node the reference's walk would return
+        std::vector<uint32_t> tied((size_t)t->count());
+        int64_t nt = 0;
+        if (pct_radius_indices_r2_q64(t->cloud, q, d2, tied.data(), (int64_t)tied.size(), &nt) != PCT_OK) { complain("kd_nearest (tie set)"); return nullptr; }
+        if (nt > 1) idx = (uint32_t)reference_tie_winner(t, q, tied.data(), std::min<int64_t>(nt, (int64_t)tied.size()));
+    }
     kdres *r = new (std::nothrow) kdres();
     if (!r) return nullptr;
     r->tree = t;

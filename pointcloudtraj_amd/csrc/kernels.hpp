@@ -1827,27 +1827,41 @@ __device__ __forceinline__ void express_done_block(const ExpressSignal &S)
     if (threadIdx.x == 0) express_done(S);
 }
 
-// one block, exact fp64 brute force over a small cloud (the RRT* node set of the kd_* drop-in)
+// one block, exact fp64 brute force over a small cloud (the RRT* node set of the kd_* drop-in).  Besides the winner (lowest index
+// among the minima) it reports HOW MANY points attain the minimum (out->count): the kd_* drop-in resolves an exact tie the way
+// the reference's tree walk does (kdtree_gpu.cpp reference_tie_winner) and only then needs the tied set.
+__device__ __forceinline__ void tie_merge(double &d, uint32_t &i, uint32_t &c, double od, uint32_t oi, uint32_t oc)
+{
+    if (od < d) { d = od; i = oi; c = oc; }
+    else if (od == d) { c += oc; i = min(i, oi); }
+}
+
 __global__ __launch_bounds__(1024) void nn_small_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                                         const float *__restrict__ z, uint32_t n, double qx, double qy, double qz,
                                                         uint32_t index_base, ExpressOut *__restrict__ out, ExpressSignal sig)
 {
     double bd = __builtin_huge_val();
-    uint32_t bi = kNoIndex;
+    uint32_t bi = kNoIndex, bc = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 1024) {
         const double d2 = dist2((double)x[i], (double)y[i], (double)z[i], qx, qy, qz);
-        if (d2 < bd) { bd = d2; bi = i; }
+        if (d2 < bd) { bd = d2; bi = i; bc = 1; }
+        else if (d2 == bd) bc++;
     }
-    wave_argmin(bd, bi);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(bd, off, kWave);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off, kWave), oc = (uint32_t)__shfl_xor((int)bc, off, kWave);
+        tie_merge(bd, bi, bc, od, oi, oc);
+    }
     __shared__ double s_d[16];
-    __shared__ uint32_t s_i[16];
-    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = bd; s_i[threadIdx.x >> 6] = bi; }
+    __shared__ uint32_t s_i[16], s_c[16];
+    if ((threadIdx.x & 63) == 0) { s_d[threadIdx.x >> 6] = bd; s_i[threadIdx.x >> 6] = bi; s_c[threadIdx.x >> 6] = bc; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; w++)
-            if (better(s_d[w], s_i[w], bd, bi)) { bd = s_d[w]; bi = s_i[w]; }
+        for (int w = 1; w < 16; w++) tie_merge(bd, bi, bc, s_d[w], s_i[w], s_c[w]);
         out->d2 = bd;
         out->idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+        out->count = bc;
         express_done(sig);
     }
 }

@@ -18,17 +18,18 @@ def K():
 
 
 @pytest.mark.parametrize("name", ["kd_nn_n1.npz", "kd_nn_n2.npz", "kd_nn_n17.npz", "kd_nn_n1000.npz",
-                                  "kd_nn_duplicates.npz", "kd_nn_c1_crop5m.npz"])
+                                  "kd_nn_duplicates.npz", "kd_nn_clustered.npz", "kd_nn_c1_crop5m.npz"])
 def test_kd_nearestf_golden(K, name):
+    """every row equals the compiled reference's answer -- ON EXACT TIES TOO (kd_nn_duplicates: 128 tied queries, 67 of them with
+    a winner other than the lowest index; kd_nn_clustered: 127 tied, 92 such): the drop-in replays the reference's walk order
+    among the tied nodes (kdtree.c:345-402, 432-436)"""
     g = load_golden(name)
     pts = g["points"]
     t = K.KDTree()
     t.insert(pts)
-    nq = min(len(g["queries"]), 200)
+    nq = min(len(g["queries"]), 400)
     ids, pos = t.nearest(g["queries"][:nq])
-    assert np.array_equal(ids, g["lowest_idx"][:nq])
-    untied = g["tie"][:nq] == 0
-    assert np.array_equal(ids[untied], g["ref_idx"][:nq][untied])
+    assert np.array_equal(ids, g["ref_idx"][:nq])
     assert np.array_equal(pos, pts[ids].astype(np.float64))     # kd_res_item hands back the stored fp64 position
     t.close()
 
@@ -169,10 +170,7 @@ def test_differential_sequences_against_the_port(K, oracle, seed, n, lattice):
         d = cur - q.astype(np.float64)
         d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
         assert d2[ids[0]] == d2[want] == d2.min()
-        if np.count_nonzero(d2 == d2.min()) == 1:
-            assert ids[0] == want
-        else:
-            assert ids[0] == int(np.argmin(d2))                      # documented tie rule: lowest insertion index
+        assert ids[0] == want                                        # ties included: the reference's walk order decides
         rad = float(rng.choice([0.5, 1.0, 1.5, 2.5, 0.0, 4.0]))
         got = t.range_ids(q, rad)
         rr = L.okd_nearest_rangef(ot, qp, C.c_float(rad))
