@@ -266,6 +266,10 @@ int pct_kernel_ms_history(pct_cloud *c, float *ms, int cap, int *n);
 /* algorithmic work of the last batch: points examined (sum over queries), cells examined */
 int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
 int pct_set_work_counters(pct_cloud *c, int enabled);
+/* diagnostics / tests: which form of the brute-force fp32 filter runs -- -1 automatic (expanded |p|^2 - 2 p.q form while its error
+ * band is small against the cloud's point spacing, clouds of 200 000 points or more), 0 always the direct (p - q)^2 form,
+ * 1 the expanded form whenever a bounding box exists.  Results are identical; only speed differs. */
+int pct_debug_set_filter_mode(int mode);
 /* diagnostics: the fp32 upper bounds the streaming filter used for the last batch */
 int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q);
 

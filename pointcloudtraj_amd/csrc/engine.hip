@@ -23,6 +23,7 @@
 #include "engine_internal.hpp"
 #include "kernels.hpp"
 #include "ring.hpp"
+#include "brute2.hpp"
 
 using namespace pct;
 
@@ -179,6 +180,9 @@ struct pct_cloud {
     // bumped whenever something a captured plan baked in goes away or changes meaning: workspace reallocation, a new point
     // count on a cloud without the ring index, grid build / drop, ring-index (re)configuration
     uint64_t generation = 1;
+    // contents version (bumped by every upload / append) and the bounding box last computed for it (brute2.hpp's centred filter)
+    uint64_t content_epoch = 1, bbox_epoch = 0;
+    float bbox_lo[3] = { 0, 0, 0 }, bbox_hi[3] = { 0, 0, 0 };
     // rolling-map index (ring.hpp): bucket table that appends update in place
     bool ring_on = false, ring_ready = false;
     float ring_cell_req = 0.0f;
@@ -504,6 +508,71 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
     return PCT_OK;
 }
 
+int g_filter_mode = -2;        // -2 = not read yet
+int filter_mode()
+{
+    if (g_filter_mode == -2) { const char *e = std::getenv("PCT_TILE_EXPANDED"); g_filter_mode = e ? std::atoi(e) : -1; }
+    return g_filter_mode;
+}
+
+int reg_groups()
+{
+    static const int v = [] { const char *e = std::getenv("PCT_TILE_REG_GROUPS"); const int g = e ? std::atoi(e) : 3; return (g == 2 || g == 4 || g == 6) ? g : 3; }();
+    return v;
+}
+
+// bounding box of the cloud's current contents, cached per contents version (one reduction + one read-back when stale)
+int cloud_bbox_cached(pct_cloud *c)
+{
+    if (c->bbox_epoch == c->content_epoch) return PCT_OK;
+    hipStream_t s = g_stream;
+    const int64_t n = c->count;
+    const int bblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    float *d_part = nullptr;
+    PCTCHK(dev_alloc(&d_part, (size_t)bblocks * 6));
+    bbox_partial_kernel<<<bblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_part);
+    std::vector<float> part((size_t)bblocks * 6);
+    hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    dev_free(d_part);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "bbox reduction failed: %s", hipGetErrorString(e));
+    for (int k = 0; k < 3; k++) { c->bbox_lo[k] = INFINITY; c->bbox_hi[k] = -INFINITY; }
+    for (int b = 0; b < bblocks; b++)
+        for (int k = 0; k < 3; k++) {
+            c->bbox_lo[k] = std::min(c->bbox_lo[k], part[(size_t)b * 6 + k]);
+            c->bbox_hi[k] = std::max(c->bbox_hi[k], part[(size_t)b * 6 + 3 + k]);
+        }
+    c->bbox_epoch = c->content_epoch;
+    return PCT_OK;
+}
+
+// Should the brute-force filter take the expanded form (brute2.hpp)?  Only while its absolute error band, ~14 u R^2 (u = 2^-24,
+// R = half diagonal of the bounding box), stays small against the squared point spacing of the cloud -- otherwise the band, not
+// the sampled bound, decides how many pairs pass.  Fills the centre / R^2 the kernels need.
+bool use_expanded_filter(pct_cloud *c, CentreDesc *out)
+{
+    const int mode = filter_mode();                              // 0 = never, 1 = whenever valid, -1 = auto
+    if (mode == 0 || c->host_mapped || c->capturing || c->count < 4) return false;
+    if (mode < 0 && c->count < 200000) return false;             // small clouds: the bounding-box pass would cost more than it saves
+    if (cloud_bbox_cached(c) != PCT_OK) return false;
+    double h[3], R2 = 0.0, vol = 8.0;
+    float ctr[3];
+    for (int k = 0; k < 3; k++) {
+        if (!std::isfinite(c->bbox_lo[k]) || !std::isfinite(c->bbox_hi[k])) return false;
+        ctr[k] = (float)(0.5 * ((double)c->bbox_lo[k] + (double)c->bbox_hi[k]));
+        h[k] = std::max((double)c->bbox_hi[k] - (double)ctr[k], (double)ctr[k] - (double)c->bbox_lo[k]);
+        R2 += h[k] * h[k];
+        vol *= h[k];
+    }
+    R2 *= 1.000001;
+    if (!std::isfinite(R2) || R2 > 1e30) return false;
+    const double spacing2 = std::pow(vol / (double)c->count, 2.0 / 3.0);
+    if (mode < 0 && !(14.0 * 0x1p-24 * R2 <= 0.25 * spacing2)) return false;
+    out->cx = ctr[0]; out->cy = ctr[1]; out->cz = ctr[2];
+    out->R2 = R2;
+    return true;
+}
+
 constexpr int kMaxTileParts = 8192;      // tile kernel: at most this many point chunks per launch
 constexpr uint32_t kChunkGroupsMax = 3072;   // 3 * 3072 * 16 B = 144 KiB of the CU's 160 KiB LDS
 
@@ -552,6 +621,55 @@ int nn_stream_filtered_slice(pct_cloud *c, const float *d_qf, int64_t qoff, int6
                                                                    reinterpret_cast<float *>(c->d_part_idx), sblocks);
     bound_reduce_kernel<<<(int)Q, 256, 0, s>>>(reinterpret_cast<const float *>(c->d_part_idx), sblocks, d_bound);
     static const bool candidates = [] { const char *e = std::getenv("PCT_TILE_CANDIDATES"); return e ? std::atoi(e) != 0 : true; }();
+    CentreDesc CD{};
+    if (candidates && use_expanded_filter(c, &CD)) {
+        // expanded form (brute2.hpp): 3 FMAs per pair on centred coordinates, thresholds widened by the proven error band
+        static const int gpi = [] { const char *e = std::getenv("PCT_TILE_GROUPS"); return e ? std::atoi(e) : 2; }();
+        static bool attr3 = false;
+        if (!attr3) {
+            const int lds = (int)(3 * kChunkGroupsMax * sizeof(float4));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_candidates2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_candidates2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(nn_tile_candidates2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            attr3 = true;
+        }
+        float4 *qprep = c->d_qsorted + qoff;                     // the query-sort records are idle on this path
+        brute2_prep_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(CD, d_qf, d_bound, (uint32_t)Q, qprep);
+        dom_begin(c, s);
+        int cq = 0;
+        const int cslices = slices_for(nblocks, &cq);
+        const dim3 grid(nblocks, cslices);
+        const size_t lds = 3 * (size_t)chunk * sizeof(float4);
+        static const bool reg_points = [] { const char *e = std::getenv("PCT_TILE_REG"); return e ? std::atoi(e) != 0 : true; }();
+        if (reg_points) {       // points held in registers (brute2.hpp tile_reg_kernel): a block covers 4096 points, no LDS
+            const int rg = reg_groups();
+            const int rblocks = (int)std::max<int64_t>(1, (ngroups + 256 * rg - 1) / (256 * rg));
+            int rq = 0;
+            const int rslices = slices_for(rblocks, &rq);
+            const dim3 rgrid(rblocks, rslices);
+            switch (rg) {
+            case 2: tile_reg_kernel<false, 2><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, qprep, d_q64, nullptr, (int)Q, rq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx, nullptr); break;
+            case 4: tile_reg_kernel<false, 4><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, qprep, d_q64, nullptr, (int)Q, rq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx, nullptr); break;
+            case 6: tile_reg_kernel<false, 6><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, qprep, d_q64, nullptr, (int)Q, rq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx, nullptr); break;
+            default: tile_reg_kernel<false, 3><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, qprep, d_q64, nullptr, (int)Q, rq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx, nullptr); break;
+            }
+        } else if (gpi == 1)
+            nn_tile_candidates2_kernel<1><<<grid, 256, lds, s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, CD, qprep, d_q64, (int)Q, cq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx);
+        else if (gpi == 4)
+            nn_tile_candidates2_kernel<4><<<grid, 256, lds, s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, CD, qprep, d_q64, (int)Q, cq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx);
+        else
+            nn_tile_candidates2_kernel<2><<<grid, 256, lds, s>>>(c->x, c->y, c->z, (uint32_t)c->count, chunk, CD, qprep, d_q64, (int)Q, cq, c->d_cand_count, c->d_cand_d2, c->d_cand_idx);
+        dom_end(c, s);
+        HIPCHK(hipMemsetAsync(c->d_ovf, 0, sizeof(uint32_t), s));
+        nn_reduce_candidates_kernel<<<(int)Q, 256, 0, s>>>(c->d_cand_count, c->d_cand_d2, c->d_cand_idx, (uint32_t)c->index_base, c->d_ovf, d_idx, d_d2);
+        nn_overflow_scan_kernel<<<kOvfBlocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, d_q64, c->d_ovf, c->d_part_d2, c->d_part_idx);
+        nn_overflow_fold_kernel<<<(int)Q, 256, 0, s>>>(c->d_ovf, c->d_part_d2, c->d_part_idx, kOvfBlocks, (uint32_t)c->index_base, d_idx, d_d2);
+        end_timing(c, s);
+        HIPCHK(hipGetLastError());
+        c->host_work = true;
+        c->host_points = (uint64_t)Q * (uint64_t)c->count;
+        return PCT_OK;
+    }
     if (candidates) {       // survivors of the bound go to per-query candidate lists: no per-tile block reductions, no partial arrays
         static bool attr2 = false;
         if (!attr2) {
@@ -698,6 +816,32 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
     }
     if (algo != PCT_ALGO_STREAM) return fail(PCT_ERR_INVALID, "unknown algo %d", algo);
     widen_queries_kernel<<<ceil_div(3 * Q, 256), 256, 0, s>>>(d_q, (uint32_t)(3 * Q), c->d_q64);
+    CentreDesc CD{};
+    static const int64_t count_filter_min_q = [] { const char *e = std::getenv("PCT_COUNT_FILTER_MIN_Q"); return e ? std::atoll(e) : 16ll; }();
+    if (Q >= count_filter_min_q && use_expanded_filter(c, &CD)) {
+        // packed-fp32 filter in expanded form + exact fp64 test of whatever may lie inside the ball (brute2.hpp tile_reg_kernel<true>)
+        const int64_t ngroups = c->count >> 2;
+        const int rg = reg_groups();
+        const int rblocks = (int)std::max<int64_t>(1, (ngroups + 256 * rg - 1) / (256 * rg));
+        const int tiles = (int)((Q + kTileQ - 1) / kTileQ);
+        const int slices = std::max(1, std::min(tiles, (2048 + rblocks - 1) / rblocks));
+        const int rq = ((tiles + slices - 1) / slices) * kTileQ;
+        const int rslices = (int)((Q + rq - 1) / rq);
+        begin_timing(c, s);
+        brute2_prep_count_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(CD, d_q, d_r, (uint32_t)Q, c->d_qsorted, c->d_r2);
+        dom_begin(c, s);
+        const dim3 rgrid(rblocks, rslices);
+        switch (rg) {
+        case 2: tile_reg_kernel<true, 2><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, c->d_qsorted, c->d_q64, c->d_r2, (int)Q, rq, nullptr, nullptr, nullptr, d_count); break;
+        case 4: tile_reg_kernel<true, 4><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, c->d_qsorted, c->d_q64, c->d_r2, (int)Q, rq, nullptr, nullptr, nullptr, d_count); break;
+        case 6: tile_reg_kernel<true, 6><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, c->d_qsorted, c->d_q64, c->d_r2, (int)Q, rq, nullptr, nullptr, nullptr, d_count); break;
+        default: tile_reg_kernel<true, 3><<<rgrid, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)c->count, CD, c->d_qsorted, c->d_q64, c->d_r2, (int)Q, rq, nullptr, nullptr, nullptr, d_count); break;
+        }
+        dom_end(c, s);
+        end_timing(c, s);
+        HIPCHK(hipGetLastError());
+        return PCT_OK;
+    }
     square_radii_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(d_r, (uint32_t)Q, c->d_r2);
     const int blocks = stream_blocks(c->count);
     begin_timing(c, s);
@@ -1779,6 +1923,13 @@ int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q)
     if (!c || !out || Q > c->qcap) return fail(PCT_ERR_INVALID, "bad arguments");
     HIPCHK(hipStreamSynchronize(g_stream));
     HIPCHK(hipMemcpy(out, c->d_bound, sizeof(float) * Q, hipMemcpyDeviceToHost));
+    return PCT_OK;
+}
+
+int pct_debug_set_filter_mode(int mode)
+{
+    if (mode < -1 || mode > 1) return fail(PCT_ERR_INVALID, "filter mode must be -1 (automatic), 0 (direct form) or 1 (expanded form)");
+    g_filter_mode = mode;
     return PCT_OK;
 }
 

@@ -547,8 +547,6 @@ __global__ __launch_bounds__(256) void merge_mask_kernel(const double *__restric
     cand[i] = (d == d2_best[i] && d < __builtin_huge_val() && ix <= 0x7FFFFFFEu) ? (int32_t)ix : 0x7FFFFFFF;
 }
 
-// one 256-thread block per query folds the per-block partials (loads issued back to back,
-// compared afterwards); adds the shard's index base
 // behind the second reduction: the merged int32 candidates back to the engine's index convention (INT32_MAX = no shard holds a point)
 __global__ __launch_bounds__(256) void merge_finish_kernel(const int32_t *__restrict__ cand, uint32_t *__restrict__ idx, uint32_t Q)
 {
@@ -556,6 +554,8 @@ __global__ __launch_bounds__(256) void merge_finish_kernel(const int32_t *__rest
     if (i < Q) idx[i] = cand[i] == 0x7FFFFFFF ? kNoIndex : (uint32_t)cand[i];
 }
 
+// one 256-thread block per query folds the per-block partials (loads issued back to back,
+// compared afterwards); adds the shard's index base
 __global__ __launch_bounds__(256) void nn_reduce_partials_kernel(const double *__restrict__ part_d2,
                                                                  const uint32_t *__restrict__ part_idx, int nparts,
                                                                  uint32_t index_base, uint32_t *__restrict__ out_idx,

@@ -138,6 +138,11 @@ def sync():
     _chk(lib().pct_sync())
 
 
+def set_filter_mode(mode: int):
+    """-1 automatic, 0 direct (p-q)^2 filter, 1 expanded |p|^2 - 2 p.q filter (pct_debug_set_filter_mode); results are identical"""
+    _chk(lib().pct_debug_set_filter_mode(int(mode)))
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

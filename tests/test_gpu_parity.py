@@ -211,6 +211,17 @@ def test_filter_adversarial_near_ties(E, oracle):
     for a in (E.ALGO_STREAM, E.ALGO_STREAM_EXACT):
         i1, d1 = c.nn(q, a)
         assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64))
+    # both forms of the fp32 filter, forced (the expanded |p|^2 - 2 p.q form carries an absolute error band: here it is wider than
+    # the shell, so every shell point must reach the exact path), NN and radius counts with the radius ON the shell
+    rq = np.float32([3.0, 3.0000002, 2.9999998, 1e-3, 0.0] * 7)[:len(q)]
+    wc = oracle.brute_count(pts, q, rq)
+    for mode in (1, 0):
+        E.set_filter_mode(mode)
+        i1, d1 = c.nn(q, E.ALGO_STREAM)
+        cnt = c.radius_count(q, rq, E.ALGO_STREAM)
+        E.set_filter_mode(-1)
+        assert np.array_equal(d1, bd) and np.array_equal(i1.astype(np.int64), bi.astype(np.int64)), mode
+        assert np.array_equal(cnt.astype(np.int64), wc.astype(np.int64)), mode
     c.build_grid()
     i2, d2 = c.nn(q, E.ALGO_GRID)
     assert np.array_equal(d2, bd) and np.array_equal(i2.astype(np.int64), bi.astype(np.int64))

@@ -62,6 +62,15 @@ def test_randomised_paths_agree():
         r = np.float32(ext * float(rng.choice([0.0, 0.01, 0.08, 0.3])))
         rad = np.full(len(q), r, np.float32)
         cb = c.radius_count(q[:2000], rad[:2000], E.ALGO_STREAM)
+        # both forms of the fp32 filter, forced: the expanded |p|^2 - 2 p.q form (brute2.hpp; here also on clouds whose error band
+        # is far wider than their point spacing -- offsets 50x the extent, duplicates, lattices) and the direct (p - q)^2 form
+        for mode in (1, 0):
+            E.set_filter_mode(mode)
+            im, dm = c.nn(q, E.ALGO_STREAM)
+            cm = c.radius_count(q[:2000], rad[:2000], E.ALGO_STREAM)
+            E.set_filter_mode(-1)
+            assert np.array_equal(dm, d1) and np.array_equal(im, i1), name + f" filter mode {mode}"
+            assert np.array_equal(cm, cb), name + f" count, filter mode {mode}"
         c.build_grid()
         i3, d3 = c.nn(q, E.ALGO_GRID)
         cg = c.radius_count(q[:2000], rad[:2000], E.ALGO_GRID)
