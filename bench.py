@@ -126,6 +126,77 @@ def replan_probe(E, synth, ticks=200):
     return out
 
 
+def c4_probe(E, synth, torch, device, Q):
+    """Config C4 on ONE card: the whole 100 M-point cloud (seed 6, [0,200)^3) resident -- 1.2 GB SoA + 1.6 GB cell-sorted, far beyond
+    the 256 MiB Infinity Cache, so these are the DRAM-resident figures of both kernel families (scripts/probe_c4.py runs it alone,
+    under rocprofv3: profiles/r02_c4_*)."""
+    out = {}
+    p4 = synth.uniform_points(6, 100_000_000, 0.0, 200.0)
+    q4 = synth.uniform_points(7, 4096, 0.0, 200.0)
+    with E.Cloud(len(p4)) as c4:
+        t1 = time.perf_counter()
+        c4.set_input(p4)
+        t2 = time.perf_counter()
+        c4.build_grid()
+        E.sync()
+        t3 = time.perf_counter()
+        c4.nn(q4, E.ALGO_GRID)
+        ts = []
+        for _ in range(5):
+            t4 = time.perf_counter()
+            i4, d4 = c4.nn(q4, E.ALGO_GRID)
+            ts.append(1e3 * (time.perf_counter() - t4))
+        t5 = time.perf_counter()
+        ib, db = c4.nn(q4[:512], E.ALGO_STREAM)
+        t6 = time.perf_counter()
+        # (a) streaming kernel, one pass over 1.2 GB of SoA per launch
+        cs4 = torch.cuda.current_stream().cuda_stream
+        c4.reserve_queries(Q)
+        qd = torch.from_numpy(synth.uniform_points(5, Q, 0.0, 200.0)).to(device)
+        oi = torch.empty(Q, dtype=torch.int32, device=device)
+        od = torch.empty(Q, dtype=torch.float64, device=device)
+        sp = []
+        for qn in (1, 2, 4):
+            ms = []
+            for k in range(8):
+                c4.nn_device(qd.data_ptr(), qn, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_STREAM)
+                if k >= 2:
+                    ms.append(c4.last_kernel_ms())
+            m = float(np.median(ms))
+            sb = 12 * len(p4) + 24 * qn
+            sp.append({"queries": qn, "kernel_ms": m, "algorithmic_bytes": sb, "achieved_GBs": sb / (m * 1e-3) / 1e9,
+                       "frac_of_hbm_peak": sb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        # (b) the 1 M-query throughput batch through the index
+        for _ in range(2):
+            c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+        torch.cuda.synchronize()
+        t7 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+        torch.cuda.synchronize()
+        step4 = 1e3 * (time.perf_counter() - t7) / reps
+        k4 = float(np.mean(c4.kernel_ms_history(reps)))
+        c4.set_work_counters(True)
+        c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
+        torch.cuda.synchronize()
+        ps4, runs4 = c4.last_work()
+        c4.set_work_counters(False)
+        alg4 = 12 * ps4 + 8 * runs4 + 24 * Q
+        del qd, oi, od
+    out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted, beyond the 256 MiB Infinity Cache)",
+                       "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_4096_queries_ms_host_buffers": float(np.median(ts)),
+                       "brute_force_512_queries_ms": 1e3 * (t6 - t5), "brute_force_pair_evals_per_s": 512 * 1e8 / (t6 - t5),
+                       "indexed_equals_brute_force": bool(np.array_equal(ib, i4[:512]) and np.array_equal(db, d4[:512])),
+                       "stream_kernel": {"kernel": "nn_stream_kernel<QT> (all-fp64, one pass over the SoA cloud)", "points": sp},
+                       "grid_throughput": {"queries": Q, "ms_per_step": step4, "queries_per_s": Q / (step4 * 1e-3), "kernel": "nn_grid_coop_kernel",
+                                           "kernel_ms": k4, "algorithmic_bytes": int(alg4), "achieved_GBs": alg4 / (k4 * 1e-3) / 1e9,
+                                           "frac_of_hbm_peak": alg4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "points_scanned": int(ps4), "cell_runs": int(runs4)}}
+    del p4
+    return out["c4_probe"]
+
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,6 +211,7 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=0, help="points in the host kd-tree (0 = same as --points)")
     ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming / brute-force / corridor probes (0 = skip)")
     ap.add_argument("--replan-probe", type=int, default=1, help="config C5: rolling 5M-point cloud, 20 Hz replan ticks (0 = skip)")
+    ap.add_argument("--c4-probe", type=int, default=1, help="N = 1: also run the 100 M-point cloud (config C4) on this one card (0 = skip)")
     ap.add_argument("--one-gpu-ref", type=int, default=1, help="N > 1: rank 0 also times the batch against the whole cloud on its one card (0 = skip)")
     return ap.parse_args()
 
@@ -422,10 +494,18 @@ def main():
         # (b) brute force at config C2's batch size: LDS-tiled packed-fp32 filter + exact fp64 recheck
         qn = 4096
         ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 5)
-        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + nn_tile_candidates_kernel + nn_reduce_candidates_kernel",
+        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + brute2_prep_kernel + tile_reg_kernel<false> (expanded-form packed-fp32 filter, points in registers, exact fp64 recheck) + nn_reduce_candidates_kernel",
                                     "queries": qn, "kernel_ms": ms, "queries_per_s": qn / (ms * 1e-3),
                                     "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
-                                    "flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}
+                                    "algorithmic_flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}
+        # the same batch as a radius count (kd_nearest_range + kd_res_size semantics) through the brute-force family
+        r4 = torch.full((qn,), 1.0, dtype=torch.float32, device=sc.device)
+        cnt4 = torch.empty(qn, dtype=torch.int32, device=sc.device)
+        ms = timed(lambda: sc.cloud.radius_count_device(q.data_ptr(), r4.data_ptr(), qn, cnt4.data_ptr(), cs, E.ALGO_STREAM), 5)
+        out["brute_force_count_probe"] = {"kernel": "brute2_prep_count_kernel + tile_reg_kernel<true> (same filter, exact fp64 test of what may lie inside the ball)",
+                                          "queries": qn, "radius": 1.0, "kernel_ms": ms, "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
+                                          "mean_count": float(cnt4.double().mean().item())}
+        del r4, cnt4
         # (c) corridor side (config C3): sphere inflation of 200 seeds against the 10M-point cloud through the
         # host-buffer entry point (PCIe and launch latency included) -- ms per pass
         seeds = synth.uniform_points(4, 200, 10.0, 90.0).astype(np.float64)
@@ -507,71 +587,8 @@ def main():
         vm.close()
         del d_pts
 
-    if a.replan_probe and world == 1:
-        # config C4 on ONE card: the whole 100 M-point cloud (seed 6, [0,200)^3) resident -- 1.2 GB SoA + 1.6 GB cell-sorted, far
-        # beyond the 256 MiB Infinity Cache, so these are the DRAM-resident figures of both kernel families
-        p4 = synth.uniform_points(6, 100_000_000, 0.0, 200.0)
-        q4 = synth.uniform_points(7, 4096, 0.0, 200.0)
-        with E.Cloud(len(p4)) as c4:
-            t1 = time.perf_counter()
-            c4.set_input(p4)
-            t2 = time.perf_counter()
-            c4.build_grid()
-            E.sync()
-            t3 = time.perf_counter()
-            c4.nn(q4, E.ALGO_GRID)
-            ts = []
-            for _ in range(5):
-                t4 = time.perf_counter()
-                i4, d4 = c4.nn(q4, E.ALGO_GRID)
-                ts.append(1e3 * (time.perf_counter() - t4))
-            t5 = time.perf_counter()
-            ib, db = c4.nn(q4[:512], E.ALGO_STREAM)
-            t6 = time.perf_counter()
-            # (a) streaming kernel, one pass over 1.2 GB of SoA per launch
-            cs4 = torch.cuda.current_stream().cuda_stream
-            c4.reserve_queries(Q)
-            qd = torch.from_numpy(synth.uniform_points(5, Q, 0.0, 200.0)).to(sc.device)
-            oi = torch.empty(Q, dtype=torch.int32, device=sc.device)
-            od = torch.empty(Q, dtype=torch.float64, device=sc.device)
-            sp = []
-            for qn in (1, 2, 4):
-                ms = []
-                for k in range(8):
-                    c4.nn_device(qd.data_ptr(), qn, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_STREAM)
-                    if k >= 2:
-                        ms.append(c4.last_kernel_ms())
-                m = float(np.median(ms))
-                sb = 12 * len(p4) + 24 * qn
-                sp.append({"queries": qn, "kernel_ms": m, "algorithmic_bytes": sb, "achieved_GBs": sb / (m * 1e-3) / 1e9,
-                           "frac_of_hbm_peak": sb / (m * 1e-3) / 1e9 / HBM_PEAK_GBS})
-            # (b) the 1 M-query throughput batch through the index
-            for _ in range(2):
-                c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
-            torch.cuda.synchronize()
-            t7 = time.perf_counter()
-            reps = 10
-            for _ in range(reps):
-                c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
-            torch.cuda.synchronize()
-            step4 = 1e3 * (time.perf_counter() - t7) / reps
-            k4 = float(np.mean(c4.kernel_ms_history(reps)))
-            c4.set_work_counters(True)
-            c4.nn_device(qd.data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs4, E.ALGO_GRID)
-            torch.cuda.synchronize()
-            ps4, runs4 = c4.last_work()
-            c4.set_work_counters(False)
-            alg4 = 12 * ps4 + 8 * runs4 + 24 * Q
-            del qd, oi, od
-        out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted, beyond the 256 MiB Infinity Cache)",
-                           "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_4096_queries_ms_host_buffers": float(np.median(ts)),
-                           "brute_force_512_queries_ms": 1e3 * (t6 - t5), "brute_force_pair_evals_per_s": 512 * 1e8 / (t6 - t5),
-                           "indexed_equals_brute_force": bool(np.array_equal(ib, i4[:512]) and np.array_equal(db, d4[:512])),
-                           "stream_kernel": {"kernel": "nn_stream_kernel<QT> (all-fp64, one pass over the SoA cloud)", "points": sp},
-                           "grid_throughput": {"queries": Q, "ms_per_step": step4, "queries_per_s": Q / (step4 * 1e-3), "kernel": "nn_grid_coop_kernel",
-                                               "kernel_ms": k4, "algorithmic_bytes": int(alg4), "achieved_GBs": alg4 / (k4 * 1e-3) / 1e9,
-                                               "frac_of_hbm_peak": alg4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "points_scanned": int(ps4), "cell_runs": int(runs4)}}
-        del p4
+    if a.c4_probe and world == 1:
+        out["c4_probe"] = c4_probe(E, synth, torch, sc.device, Q)
 
     if a.cpu_queries > 0 and world == 1:
         ncpu = a.cpu_points or a.points
