@@ -42,11 +42,12 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 def measured_traffic(kernel: str):
     """(HBM bytes per launch, file) of `kernel` from the newest committed PMC summary of this same command
-    (scripts/prof_bench.sh -> profiles/*_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes, the gfx950 correction of
+    (scripts/prof_r2.sh bench -> profiles/*_bench_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes, the gfx950 correction of
     MI355X_MICROARCH.md).  (None, None) when no summary is committed (PMC counters cannot be collected inside the timed run)."""
     import glob
     best, src = None, None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "*_final_pmc.json")))
+    for f in files:
         try:
             d = json.load(open(f))
         except (OSError, ValueError):

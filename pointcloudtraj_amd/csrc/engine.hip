@@ -482,7 +482,13 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         // the key array costs 4 B per query written by one pass and read by the next: the scatter pass recomputes keys instead
         static const bool store_keys = [] { const char *e = std::getenv("PCT_SORT_STORE_KEYS"); return e ? std::atoi(e) != 0 : false; }();
         uint32_t *keys = store_keys ? c->d_qbin : nullptr;
-        qsort_hist_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, per_block, keys, total1, fill1, pingpong ? total1_next : nullptr);
+        // the histogram pass only adds into the global totals, so it can use shorter slices than the scatter pass (whose writes want
+        // long per-block runs); more blocks measured SLOWER though (PCT_SORT_HIST_DIV = 1 / 2 / 4 / 8: 0.165 / 0.167 / 0.169 / 0.179 ms
+        // per step, same box), so the default keeps one slice size for both
+        static const int hist_div = [] { const char *e = std::getenv("PCT_SORT_HIST_DIV"); return e ? std::max(1, std::min(8, std::atoi(e))) : 1; }();
+        const uint32_t hist_per_block = std::max<uint32_t>(1024u, (per_block / (uint32_t)hist_div) / 1024u * 1024u);
+        qsort_hist_kernel<<<ceil_div(Q, (int64_t)hist_per_block), 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, hist_per_block, keys, total1, fill1,
+                                                                              pingpong ? total1_next : nullptr);
         if (levels == 1) {
             qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, c->d_perm, c->d_inv);
             if (pingpong) c->sort_phase ^= 1;

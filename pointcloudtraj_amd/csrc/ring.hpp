@@ -138,9 +138,11 @@ __global__ __launch_bounds__(256) void ring_evict_kernel(RingDesc R, const float
 __global__ __launch_bounds__(256) void ring_insert_kernel(RingDesc R, float *__restrict__ x, float *__restrict__ y, float *__restrict__ z,
                                                           const unsigned char *__restrict__ src, uint32_t stride, uint32_t n,
                                                           uint32_t slot0, uint2 *__restrict__ ht, float4 *__restrict__ slots,
-                                                          float4 *__restrict__ ovf, uint32_t *__restrict__ where, RingState *__restrict__ st)
+                                                          float4 *__restrict__ ovf, uint32_t *__restrict__ where, RingState *__restrict__ st,
+                                                          uint32_t new_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && new_count != 0xFFFFFFFFu) st->count = new_count;     // the append's last launch publishes the window's new size
     if (i >= n) return;
     const uint32_t slot = slot0 + i;
     const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
@@ -288,13 +290,16 @@ struct ReplanHeader {
 };
 
 struct ReplanSummary { long long first_hit_sample, first_hit_ctrl; int32_t n_nodes, n_samples, n_ctrl; uint32_t seq; };
+// device words the blocks of one batch meet on: a ticket counter and the running first-hit minima (reset by the last block)
+struct ReplanMeet { uint32_t ticket; int32_t first_sample, first_ctrl; uint32_t pad; };
 
 template <bool RING>
 __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc G0, const float4 *__restrict__ pts0,
                                                            const uint32_t *__restrict__ cs0, CoarseLevels C, int static_count,
                                                            const ReplanHeader *__restrict__ hdr, const double *__restrict__ f64a,
                                                            const uint32_t *__restrict__ u32a, uint32_t index_base,
-                                                           ExpressOut *__restrict__ out, double *__restrict__ pos_out)
+                                                           ExpressOut *__restrict__ out, double *__restrict__ pos_out,
+                                                           ReplanMeet *__restrict__ meet, ReplanSummary *__restrict__ sum)
 {
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
@@ -302,7 +307,8 @@ __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc 
     __shared__ double s_pos[3];
     const ReplanHeader H = *hdr;
     const int slot = (int)blockIdx.x;
-    if (slot >= H.n_nodes + H.n_samples + H.n_ctrl) return;
+    const int total = H.n_nodes + H.n_samples + H.n_ctrl;
+    if (slot >= total) return;
     const InflateParams P = H.P;
     double px, py, pz;
     if (slot < H.n_nodes) {
@@ -336,55 +342,53 @@ __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc 
         const double *c = f64a + H.off_coef + (size_t)seg * H.row_stride;
         px = c[j] * T; py = c[m + j] * T; pz = c[2 * m + j] * T;
     }
-    if (threadIdx.x < 3 && slot >= H.n_nodes) pos_out[3 * (size_t)(slot - H.n_nodes) + threadIdx.x] = threadIdx.x == 0 ? px : threadIdx.x == 1 ? py : pz;
     const double dx = px - P.sx, dy = py - P.sy, dz = pz - P.sz;
     const bool empty = RING ? V.st->count == 0 : static_count == 0;
-    if (empty || sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius) {          // corridor_finder.cpp:115-116
-        if (threadIdx.x == 0) { out[slot].radius = P.max_radius - P.search_margin; out[slot].idx = kNoIndex; out[slot].d2 = __builtin_huge_val(); out[slot].count = 0; }
-        return;
-    }
-    const double reach = P.max_radius + P.search_margin;
-    const double stop_d2 = H.want_nn ? __builtin_huge_val() : reach * reach;
-    double bd;
-    uint32_t bi;
-    if (RING) ring_block_nn_search(V, px, py, pz, stop_d2, s_d, s_i, bd, bi);
-    else block_nn_search(G0, pts0, cs0, C, px, py, pz, stop_d2, s_d, s_i, bd, bi);
-    if (threadIdx.x == 0) {
+    double bd = __builtin_huge_val(), radius = P.max_radius - P.search_margin;
+    uint32_t bi = kNoIndex;
+    if (!(empty || sqrt(dx * dx + dy * dy + dz * dz) > P.sample_range + P.max_radius)) {        // corridor_finder.cpp:115-116
+        const double reach = P.max_radius + P.search_margin;
+        const double stop_d2 = H.want_nn ? __builtin_huge_val() : reach * reach;
+        if (RING) ring_block_nn_search(V, px, py, pz, stop_d2, s_d, s_i, bd, bi);
+        else block_nn_search(G0, pts0, cs0, C, px, py, pz, stop_d2, s_d, s_i, bd, bi);
         const double rr = sqrt(bd) - P.search_margin;
-        out[slot].radius = rr < P.max_radius ? rr : P.max_radius;
+        radius = rr < P.max_radius ? rr : P.max_radius;
+    }
+    // Thread 0 hands the block's result to the caller's (host-visible) buffer, joins the first-hit minima and takes a ticket; the
+    // block holding the last ticket writes the summary and, last of all, the sequence word the host polls (system-scope release).
+    // No second kernel: a separate one-block "finish" launch cost 8.9 us of a 23 us batch (profiles/r02_c5_kernel_stats.csv).
+    if (threadIdx.x == 0) {
+        out[slot].radius = radius;
         out[slot].idx = (bi == kNoIndex) ? kNoIndex : bi + index_base;
         out[slot].d2 = bd;
         out[slot].count = 0;
+        if (slot >= H.n_nodes) { double *po = pos_out + 3 * (size_t)(slot - H.n_nodes); po[0] = px; po[1] = py; po[2] = pz; }
+        if (radius < 0.0) {
+            if (slot >= H.n_nodes && slot < H.n_nodes + H.n_samples) atomicMin(&meet->first_sample, slot - H.n_nodes);
+            else if (slot >= H.n_nodes + H.n_samples) atomicMin(&meet->first_ctrl, slot - H.n_nodes - H.n_samples);
+        }
+        __threadfence_system();
+        if (atomicAdd(&meet->ticket, 1u) == (uint32_t)total - 1u) {
+            __threadfence_system();
+            const int fs = atomicExch(&meet->first_sample, 0x7FFFFFFF), fc = atomicExch(&meet->first_ctrl, 0x7FFFFFFF);
+            atomicExch(&meet->ticket, 0u);
+            sum->first_hit_sample = fs == 0x7FFFFFFF ? -1ll : (long long)fs;
+            sum->first_hit_ctrl = fc == 0x7FFFFFFF ? -1ll : (long long)fc;
+            sum->n_nodes = H.n_nodes; sum->n_samples = H.n_samples; sum->n_ctrl = H.n_ctrl;
+            __threadfence_system();
+            __hip_atomic_store(&sum->seq, H.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
-// first colliding sample / control point (radius < 0), and the results handed to the caller's (host-visible) buffer in one sweep
-__global__ __launch_bounds__(256) void replan_finish_kernel(const ReplanHeader *__restrict__ hdr, const ExpressOut *__restrict__ res,
-                                                            ExpressOut *__restrict__ res_host, ReplanSummary *__restrict__ sum)
+// a batch with no planner point at all still has to answer: summary only (one thread; returns at once otherwise)
+__global__ void replan_empty_kernel(const ReplanHeader *__restrict__ hdr, ReplanSummary *__restrict__ sum)
 {
-    __shared__ int s_fs, s_fc;
-    if (threadIdx.x == 0) { s_fs = 0x7FFFFFFF; s_fc = 0x7FFFFFFF; }
-    __syncthreads();
-    const int nn = hdr->n_nodes, ns = hdr->n_samples, nc = hdr->n_ctrl;
-    int fs = 0x7FFFFFFF, fc = 0x7FFFFFFF;
-    for (int i = (int)threadIdx.x; i < nn + ns + nc; i += 256) {
-        const ExpressOut e = res[i];
-        if (res_host) res_host[i] = e;
-        if (e.radius < 0.0) {
-            if (i >= nn && i < nn + ns) fs = min(fs, i - nn);
-            else if (i >= nn + ns) fc = min(fc, i - nn - ns);
-        }
-    }
-    atomicMin(&s_fs, fs);
-    atomicMin(&s_fc, fc);
-    __threadfence_system();                     // this thread's records are in the caller's buffer before the block goes on
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sum->first_hit_sample = s_fs == 0x7FFFFFFF ? -1ll : (long long)s_fs;
-        sum->first_hit_ctrl = s_fc == 0x7FFFFFFF ? -1ll : (long long)s_fc;
-        sum->n_nodes = nn; sum->n_samples = ns; sum->n_ctrl = nc;
-        __hip_atomic_store(&sum->seq, hdr->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // last: the host polls this word
-    }
+    if (hdr->n_nodes + hdr->n_samples + hdr->n_ctrl != 0) return;
+    sum->first_hit_sample = -1; sum->first_hit_ctrl = -1;
+    sum->n_nodes = 0; sum->n_samples = 0; sum->n_ctrl = 0;
+    __threadfence_system();
+    __hip_atomic_store(&sum->seq, hdr->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // plain NN / inflation of a device batch over a ring-indexed cloud: a block per query (the rolling map serves the planner's
