@@ -267,3 +267,88 @@ def test_ctrl_points_check_every_index_kind(E, oracle):
             assert np.array_equal(cp["pos"], ref["ctrl_pos"]) and np.array_equal(cp["radius"], ref["ctrl_radius"]), (kind, t_start)
             assert np.array_equal(cp["d2"], ref["ctrl_d2"]), (kind, t_start)
             c.close()
+
+
+def test_ring_index_degenerate_clouds(E, oracle):
+    """one point, all points identical (everything beyond 32 spills to the overflow queue), capacity smaller than a frame, an
+    index requested on a populated cloud, drop + the cell-sorted index afterwards"""
+    q = np.float32([[0.5, 0.5, 0.5], [3, 3, 3], [-7, 2, 9]])
+    c = E.Cloud(1)
+    c.ring_index()
+    c.append(np.float32([[1, 2, 3]]))
+    i, d = c.nn(q)
+    assert np.array_equal(i, [0, 0, 0]) and np.array_equal(d, ((np.float64([1, 2, 3]) - q.astype(np.float64)) ** 2).sum(1))
+    c.append(np.float32([[0.5, 0.5, 0.5]]))            # evicts the only point
+    i, d = c.nn(q)
+    assert np.array_equal(i, [0, 0, 0]) and d[0] == 0.0
+    with pytest.raises(E.EngineError):
+        c.append(np.zeros((2, 3), np.float32))         # a frame larger than the ring
+    c.close()
+    m = Mirror(5000)
+    c = E.Cloud(5000)
+    c.ring_index()
+    for k in range(4):
+        f = np.tile(np.float32([[2.0, 2.0, 2.0]]), (2000, 1))
+        f[:10] = synth.uniform_points(k, 10, 0, 4)
+        c.append(f)
+        m.append(f)
+        check_nn(E, c, m, np.concatenate([q, f[:12]]), oracle, f"identical points, frame {k}")
+    assert c.ring_info()["overflow_entries"] > 3000
+    c.close()
+    pts = synth.uniform_points(7, 50_000, 0, 10)
+    c = E.Cloud(60_000)
+    c.set_input(pts)
+    c.ring_index(0.0, None)                            # on a populated cloud: sized from its contents, filed at once
+    assert c.has_ring_index
+    bi, bd = oracle.brute_nearest(pts, pts[:100] + np.float32(0.01))
+    i, d = c.nn(pts[:100] + np.float32(0.01))
+    assert np.array_equal(d, bd) and np.array_equal(i.astype(np.int64), bi.astype(np.int64))
+    with pytest.raises(E.EngineError):
+        c.build_grid()                                 # one index kind at a time
+    c.ring_drop()
+    c.build_grid()
+    i, d = c.nn(pts[:100] + np.float32(0.01), E.ALGO_GRID)
+    assert np.array_equal(d, bd) and np.array_equal(i.astype(np.int64), bi.astype(np.int64))
+    c.close()
+
+
+def test_ring_index_randomised_appends(E, oracle):
+    """randomised differential run of the rolling-map index: ring capacities from 1 k to 150 k, append sizes from 1 point to the
+    whole ring, uniform / clustered / duplicate-heavy / drifting frames (buckets overflow and drain again, windows wrap the
+    table), queries inside and far outside -- every step against the exhaustive oracle over the host mirror.
+    PCT_RING_FUZZ_STEPS scales it up for a manual soak."""
+    import os
+    rng = np.random.default_rng(4242)
+    steps = int(os.environ.get("PCT_RING_FUZZ_STEPS", "120"))
+    done = 0
+    while done < steps:
+        cap = int(rng.choice([1000, 5000, 40_000, 150_000]))
+        ext = float(rng.choice([1.0, 30.0, 400.0]))
+        c, m = E.Cloud(cap), Mirror(cap)
+        if rng.random() < 0.5:
+            c.ring_index()
+        else:
+            c.ring_index(ext / float(rng.choice([20, 60, 200])), (ext, ext, ext * float(rng.choice([1.0, 0.1]))))
+        drift = np.float32(rng.uniform(-0.3, 0.3, 3) * ext)
+        centre = np.zeros(3, np.float32)
+        for _ in range(int(rng.integers(4, 16))):
+            n = int(min(cap, max(1, rng.choice([1, 17, cap // 50, cap // 7, cap // 2, cap]))))
+            kind = rng.choice(["uniform", "dups", "clusters"])
+            u = rng.random((n, 3))
+            if kind == "uniform":
+                p = u * ext
+            elif kind == "dups":
+                k = max(1, n // 80)
+                p = (rng.random((k, 3)) * ext)[rng.integers(0, k, n)]
+            else:
+                cc = rng.random((5, 3)) * ext
+                p = cc[rng.integers(0, 5, n)] + rng.normal(0, ext * 0.004, (n, 3))
+            centre = centre + drift
+            f = (p * [1, 1, 0.2] + centre).astype(np.float32)
+            c.append(f)
+            m.append(f)
+            q = np.concatenate([(rng.random((60, 3)) * ext * 1.3 - 0.15 * ext) * [1, 1, 0.2] + centre, f[rng.integers(0, n, 20)],
+                                (rng.random((8, 3)) - 0.5) * ext * 30 + centre]).astype(np.float32)
+            check_nn(E, c, m, q, oracle, f"cap {cap} ext {ext} {kind} n {n}")
+            done += 1
+        c.close()
