@@ -102,6 +102,9 @@ int pct_cloud_ring_index(pct_cloud *c, float cell_size, const float extent[3]);
 int pct_cloud_ring_drop(pct_cloud *c);
 int pct_cloud_has_ring_index(const pct_cloud *c);
 int pct_cloud_ring_info(pct_cloud *c, int32_t dims[3], double *cell_size, int64_t *overflow_entries);
+/* diagnostics (tests): where ring slot `slot`'s record is filed: out = {where word, bucket of the slot's coordinates, head, tail of
+ * that bucket (or of the overflow queue, bit 31 of the where word), id word stored at the filed position, overflow queue length} */
+int pct_debug_ring_slot(pct_cloud *c, int64_t slot, uint32_t out[6]);
 
 /* Build / drop the uniform-cell index used by PCT_ALGO_GRID.  cell_size <= 0 picks one from
  * the bounding box and point count (about `pct` points per cell). */

@@ -193,6 +193,9 @@ struct pct_cloud {
     float4 *ring_slots = nullptr, *ring_ovf = nullptr;
     uint32_t *ring_where = nullptr;
     RingState *ring_st = nullptr;
+    uint32_t *h_ring_status = nullptr, *d_ring_status = nullptr;      // host-mapped {overrun flag, overflow-queue length}
+    int64_t ring_cfg_count = 0;                                       // points in the window when the table was last sized
+    int ring_appends_since_cfg = 0;
     struct ReplanCtx *rp = nullptr;              // lazily created context of the un-captured fused planner batch
 };
 
@@ -1017,6 +1020,7 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
     dev_free(c->ring_ht); dev_free(c->ring_slots); dev_free(c->ring_ovf); dev_free(c->ring_where); dev_free(c->ring_st);
+    if (c->h_ring_status) (void)hipHostFree(c->h_ring_status);
     replan_ctx_free(c->rp);
     dev_free(c->crop_tile); dev_free(c->crop_idx); dev_free(c->crop_d2); dev_free(c->crop_x); dev_free(c->crop_y); dev_free(c->crop_z);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

@@ -33,14 +33,20 @@ struct RingDesc {
     double inv_h, h;
     int gx, gy, gz;          // bucket table dimensions, powers of two
     int lx, ly;              // log2(gx), log2(gy)
-    uint32_t ovf_mask;       // overflow queue capacity - 1 (power of two >= cloud capacity: the queue itself cannot overflow)
+    // overflow queue capacity - 1.  The queue holds one entry per live spilled point plus dead entries its head has not passed yet;
+    // the head is blocked only by a live entry, and entries behind a live head that are already dead can only belong to the same
+    // insert launch as that head entry (younger launches are evicted later), so its length never exceeds capacity + one launch
+    // <= 2 x cloud capacity: the table is a power of two >= 2 x capacity + 16.  `status` (host-mapped, two words) still gets
+    // {1, length} from a launch that would overrun it and {0, length} otherwise: the host rebuilds the index from the SoA arrays.
+    uint32_t ovf_mask;
+    uint32_t *status;
 };
 
 // device-resident state the append kernels maintain and the query kernels read: a captured hipGraph stays valid across appends
 struct RingState {
     uint32_t ovf_head, ovf_tail;     // monotonic; live entries are [head, tail)
     uint32_t count;                  // valid points in the ring
-    uint32_t pad;
+    uint32_t ticket;                 // blocks of an evict launch that have finished marking (reset by the last one)
 };
 
 __device__ __forceinline__ int ring_cell_coord(double v, double inv_h, bool &wild)
@@ -91,46 +97,78 @@ __device__ __forceinline__ void ring_file(const RingDesc &R, float px, float py,
         t = seen;
     }
     const uint32_t pos = atomicAdd(&st->ovf_tail, 1u);
+    if (pos - __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > R.ovf_mask)
+        __hip_atomic_store(&R.status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // cannot happen (see RingDesc); if it does the host rebuilds
     ovf[pos & R.ovf_mask] = rec;
     where[slot] = (pos & ~kRingInOvf) | kRingInOvf;
 }
 
 // Pass 1 of an append: one thread per ring slot about to be overwritten retires the point the slot holds -- its record is
-// marked dead where it was filed, then the owning FIFO's head moves past every dead record in front (several threads may try:
-// the compare-and-swap lets each step happen once).  No record is filed while this runs.
+// marked dead where it was filed, then the owning bucket's head moves past every dead record in front (several threads may try:
+// the compare-and-swap lets each step happen once; a bucket holds at most 32 records).  The overflow queue's head is moved once
+// per launch, by the last block (below).  No record is filed while this runs.
 __global__ __launch_bounds__(256) void ring_evict_kernel(RingDesc R, const float *__restrict__ x, const float *__restrict__ y,
                                                          const float *__restrict__ z, uint32_t slot0, uint32_t n,
                                                          uint2 *__restrict__ ht, float4 *__restrict__ slots, float4 *__restrict__ ovf,
                                                          const uint32_t *__restrict__ where, RingState *__restrict__ st)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = slot0 + i;
-    const uint32_t w = where[slot];
-    if (w & kRingInOvf) {
-        uint32_t *idw = reinterpret_cast<uint32_t *>(&ovf[w & R.ovf_mask].w);
-        __hip_atomic_store(idw, kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t tail = st->ovf_tail;
-        uint32_t h = __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (h != tail) {
-            const uint32_t *hw = reinterpret_cast<const uint32_t *>(&ovf[h & R.ovf_mask].w);
-            if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
-            const uint32_t seen = atomicCAS(&st->ovf_head, h, h + 1u);
-            h = seen == h ? h + 1u : seen;
+    // the overflow queue is either empty for the whole launch (nothing is filed while it runs) or needs its head moved afterwards
+    const uint32_t q_tail = st->ovf_tail;
+    const bool queue_in_use = q_tail != st->ovf_head;
+    if (i < n) {
+        const uint32_t slot = slot0 + i;
+        const uint32_t w = where[slot];
+        if (w & kRingInOvf) {
+            uint32_t *idw = reinterpret_cast<uint32_t *>(&ovf[w & R.ovf_mask].w);
+            __hip_atomic_store(idw, kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const uint32_t b = ring_bucket_of(R, x[slot], y[slot], z[slot]);
+            float4 *base = slots + (size_t)b * kRingK;
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(&base[w & (kRingK - 1)].w), kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tail = ht[b].y;
+            uint32_t h = __hip_atomic_load(&ht[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (h != tail) {
+                const uint32_t *hw = reinterpret_cast<const uint32_t *>(&base[h & (kRingK - 1)].w);
+                if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
+                const uint32_t seen = atomicCAS(&ht[b].x, h, h + 1u);
+                h = seen == h ? h + 1u : seen;
+            }
         }
-        return;
     }
-    const uint32_t b = ring_bucket_of(R, x[slot], y[slot], z[slot]);
-    float4 *base = slots + (size_t)b * kRingK;
-    __hip_atomic_store(reinterpret_cast<uint32_t *>(&base[w & (kRingK - 1)].w), kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t tail = ht[b].y;
-    uint32_t h = __hip_atomic_load(&ht[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (h != tail) {
-        const uint32_t *hw = reinterpret_cast<const uint32_t *>(&base[h & (kRingK - 1)].w);
-        if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
-        const uint32_t seen = atomicCAS(&ht[b].x, h, h + 1u);
-        h = seen == h ? h + 1u : seen;
+    if (!queue_in_use) return;
+    // The queue's head is moved by ONE block, the last to finish marking (a ticket per block): 256 entries per step, the dead
+    // prefix measured with ballots.  (Every evicting thread advancing the head itself, as the buckets do, serialises tens of
+    // thousands of compare-and-swaps on one word once the queue is long: 59 s for a 150 k-entry queue in the fuzz test.)
+    __shared__ uint32_t s_last, s_head;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = atomicAdd(&st->ticket, 1u) == gridDim.x - 1;
+        if (last) { atomicExch(&st->ticket, 0u); __threadfence(); }
+        s_last = last ? 1u : 0u;
+        s_head = __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (!s_last) return;
+    uint32_t h = s_head;
+    for (;;) {
+        const uint32_t pos = h + threadIdx.x;
+        bool dead = false;
+        if ((int32_t)(q_tail - pos) > 0)
+            dead = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&ovf[pos & R.ovf_mask].w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kRingDead;
+        // length of the all-dead prefix of this 256-entry window: first thread that is not dead
+        __shared__ uint32_t s_first;
+        if (threadIdx.x == 0) s_first = 256u;
+        __syncthreads();
+        if (!dead) atomicMin(&s_first, threadIdx.x);
+        __syncthreads();
+        const uint32_t adv = s_first;
+        __syncthreads();
+        h += adv;
+        if (adv < 256u) break;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&st->ovf_head, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Pass 2: store the new frame in the SoA arrays and file it.  `src` = the frame, array of structures (x,y,z at byte offsets
@@ -142,7 +180,13 @@ __global__ __launch_bounds__(256) void ring_insert_kernel(RingDesc R, float *__r
                                                           uint32_t new_count)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 && new_count != 0xFFFFFFFFu) st->count = new_count;     // the append's last launch publishes the window's new size
+    if (i == 0) {
+        if (new_count != 0xFFFFFFFFu) st->count = new_count;           // the append's last launch publishes the window's new size
+        // overflow-queue length as this launch found it (a heuristic input for the host: an index whose cells are far too small or
+        // too large for the data spills most points and is re-sized from the current contents, ring_host.inc)
+        const uint32_t len = __hip_atomic_load(&st->ovf_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&R.status[1], len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (i >= n) return;
     const uint32_t slot = slot0 + i;
     const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
