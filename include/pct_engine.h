@@ -206,6 +206,18 @@ int pct_ctrl_points_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_i
  * graph capture.  An empty shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ---------------------- */
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream);
+/* Stream variants of the planner arithmetic (same results as pct_inflate_batch / pct_bezier_check, nothing crosses the bus but the
+ * trajectory's coefficients): d_pts = Q x 3 fp64 planner points on the device; d_radius[Q] required, d_idx / d_d2 optional.
+ * Reserve the batch size first (pct_cloud_reserve_queries). */
+int pct_inflate_batch_dev(pct_cloud *c, const pct_inflate_params *p, const double *d_pts, int64_t Q, double *d_radius, uint32_t *d_idx,
+                          double *d_d2, void *stream);
+/* traj's arrays are host memory (copied on the stream: keep them alive until the stream has passed the call); outputs on the device:
+ * d_radius[cap] required, d_pos[3*cap] / d_d2[cap] / d_idx[cap] optional, *d_first_hit (int64, -1 = none), *d_nsamples (int32: the
+ * number of samples the reference would evaluate; the first min(nsamples, cap) slots are valid).  cap <= 4096 and <= the reserved
+ * batch size. */
+int pct_bezier_check_dev(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflate_params *p, double t_start, double stop_time, double dt,
+                         int64_t cap, double *d_pos, double *d_radius, double *d_d2, uint32_t *d_idx, long long *d_first_hit, int32_t *d_nsamples,
+                         void *stream);
 /* Exchange step of a sharded cloud (one process per GPU): between all_reduce(min) on the squared distances and all_reduce(min) on
  * the indices, a rank offers its global index only where its own d2 equals the reduced minimum (and is finite), INT32_MAX
  * elsewhere -- so the second reduction returns the lowest global index among the ranks that tie.  Device pointers, async on

@@ -877,15 +877,20 @@ InflateParams to_dev(const pct_inflate_params *p)
 
 // pts64 (device, Q x 3) -> radius/idx/d2 in the cloud's workspaces
 // d_pts: the planner points (device-visible), default the staging buffer; d_out != nullptr: results as records in host-mapped memory
-int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_t s, const double *d_pts = nullptr, ExpressOut *d_out = nullptr)
+// o_radius / o_idx / o_d2: where the results go (default: the cloud's workspaces)
+int inflate_dev(pct_cloud *c, const pct_inflate_params *p, int64_t Q, hipStream_t s, const double *d_pts = nullptr, ExpressOut *d_out = nullptr,
+                double *o_radius = nullptr, uint32_t *o_idx = nullptr, double *o_d2 = nullptr)
 {
     const InflateParams P = to_dev(p);
+    if (!o_radius) o_radius = c->d_radius;
+    if (!o_idx) o_idx = c->d_idx;
+    if (!o_d2) o_d2 = c->d_d2;
     inflate_prologue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, d_pts ? d_pts : c->d_pts64, (uint32_t)Q, c->d_q, c->d_skip);
-    if (c->count > 0) PCTCHK(nn_dev(c, PCT_ALGO_AUTO, c->d_q, Q, c->d_idx, c->d_d2, s));
+    if (c->count > 0) PCTCHK(nn_dev(c, PCT_ALGO_AUTO, c->d_q, Q, o_idx, o_d2, s));
     if (d_out)
-        inflate_epilogue_out_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, d_out);
+        inflate_epilogue_out_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, o_idx, o_d2, d_out);
     else
-        inflate_epilogue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, c->d_idx, c->d_d2, c->d_radius);
+        inflate_epilogue_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(P, (uint32_t)Q, c->d_skip, c->count == 0 ? 1 : 0, o_idx, o_d2, o_radius);
     HIPCHK(hipGetLastError());
     return PCT_OK;
 }
@@ -1786,6 +1791,54 @@ int pct_bezier_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflat
     if (idx && m) HIPCHK(hipMemcpy(idx, c->d_idx, sizeof(uint32_t) * m, hipMemcpyDeviceToHost));
     *nsamples = ns;
     *first_hit = fh;
+    return PCT_OK;
+}
+
+// ---- stream variants of the planner arithmetic: device buffers, asynchronous on the caller's stream ------------------------------
+int pct_inflate_batch_dev(pct_cloud *c, const pct_inflate_params *p, const double *d_pts, int64_t Q, double *d_radius, uint32_t *d_idx,
+                          double *d_d2, void *stream)
+{
+    if (!c || !p || Q < 0 || (Q > 0 && (!d_pts || !d_radius))) return fail(PCT_ERR_INVALID, "bad inflate_batch_dev arguments");
+    if (Q == 0) return PCT_OK;
+    if (Q > c->qcap) return fail(PCT_ERR_INVALID, "batch of %lld exceeds reserved %lld (call pct_cloud_reserve_queries)", (long long)Q, (long long)c->qcap);
+    return inflate_dev(c, p, Q, (hipStream_t)stream, d_pts, nullptr, d_radius, d_idx, d_d2);
+}
+
+int pct_bezier_check_dev(pct_cloud *c, const pct_bezier_traj *traj, const pct_inflate_params *p, double t_start, double stop_time, double dt,
+                         int64_t cap, double *d_pos, double *d_radius, double *d_d2, uint32_t *d_idx, long long *d_first_hit, int32_t *d_nsamples,
+                         void *stream)
+{
+    if (!c || !traj || !p || !traj->polycoef || !traj->seg_time || !traj->orders || traj->nseg <= 0 || !(dt > 0) || cap <= 0 || !d_radius ||
+        !d_first_hit || !d_nsamples)
+        return fail(PCT_ERR_INVALID, "bad bezier_check_dev arguments");
+    if (cap > kBezierCapMax || cap > c->qcap) return fail(PCT_ERR_INVALID, "cap %lld exceeds %lld (4096, and the reserved batch size)", (long long)cap,
+                                                          (long long)std::min<int64_t>(kBezierCapMax, c->qcap));
+    for (int i = 0; i < traj->nseg; i++)
+        if (traj->orders[i] < 0 || traj->orders[i] > kMaxBezierOrder || 3 * (traj->orders[i] + 1) > traj->row_stride)
+            return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
+    const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
+    hipStream_t s = (hipStream_t)stream;
+    if (ncoef > c->coef_cap || (size_t)traj->nseg > c->seg_cap) {       // grow the coefficient buffers (earlier work may still read the old ones)
+        HIPCHK(hipDeviceSynchronize());
+        if (ncoef > c->coef_cap) { dev_free(c->d_coef); c->coef_cap = 0; PCTCHK(dev_alloc(&c->d_coef, ncoef)); c->coef_cap = ncoef; }
+        if ((size_t)traj->nseg > c->seg_cap) {
+            dev_free(c->d_segtime); dev_free(c->d_orders); c->seg_cap = 0;
+            PCTCHK(dev_alloc(&c->d_segtime, traj->nseg));
+            PCTCHK(dev_alloc(&c->d_orders, traj->nseg));
+            c->seg_cap = traj->nseg;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->d_coef, traj->polycoef, sizeof(double) * ncoef, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_segtime, traj->seg_time, sizeof(double) * traj->nseg, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(c->d_orders, traj->orders, sizeof(int) * traj->nseg, hipMemcpyHostToDevice, s));
+    double *pos = d_pos ? d_pos : c->d_pts64;
+    HIPCHK(hipMemsetAsync(pos, 0, sizeof(double) * 3 * cap, s));
+    BezierDesc B{ c->d_coef, c->d_segtime, c->d_orders, (int)traj->row_stride, traj->nseg, t_start, stop_time, dt, (int)cap };
+    const size_t smem = (size_t)cap * (sizeof(double) + sizeof(int));
+    bezier_samples_kernel<<<1, 256, smem, s>>>(B, pos, d_nsamples);
+    PCTCHK(inflate_dev(c, p, cap, s, pos, nullptr, d_radius, d_idx, d_d2));
+    first_hit_kernel<<<1, 256, 0, s>>>(d_radius, d_nsamples, (int)cap, d_first_hit);
+    HIPCHK(hipGetLastError());
     return PCT_OK;
 }
 

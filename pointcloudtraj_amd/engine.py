@@ -95,6 +95,9 @@ def lib():
         L.pct_bezier_check.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.c_double, C.c_double,
                                        C.POINTER(i64), C.POINTER(i64), i64, f64p, f64p, f64p, u32p]
         L.pct_nn_batch_dev.argtypes = [vp, i32, vp, i64, vp, vp, vp]
+        L.pct_inflate_batch_dev.argtypes = [vp, C.POINTER(InflateParams), vp, i64, vp, vp, vp, vp]
+        L.pct_bezier_check_dev.argtypes = [vp, C.POINTER(BezierTraj), C.POINTER(InflateParams), C.c_double, C.c_double, C.c_double, i64,
+                                           vp, vp, vp, vp, vp, vp, vp]
         L.pct_radius_count_batch_dev.argtypes = [vp, i32, vp, vp, i64, vp, vp]
         L.pct_cloud_reserve_queries.argtypes = [vp, i64]
         L.pct_plan_create_nn.argtypes = [vp, i32, i64, C.POINTER(vp)]
@@ -338,6 +341,16 @@ class Cloud:
     # device-buffer variants: raw pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle
     def nn_device(self, q_ptr: int, Q: int, idx_ptr: int, d2_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
         _chk(lib().pct_nn_batch_dev(self._h, algo, q_ptr, int(Q), idx_ptr, d2_ptr, stream))
+
+    def inflate_device(self, params: InflateParams, pts_ptr: int, Q: int, radius_ptr: int, idx_ptr: int = 0, d2_ptr: int = 0, stream: int = 0):
+        _chk(lib().pct_inflate_batch_dev(self._h, C.byref(params), pts_ptr, int(Q), radius_ptr, idx_ptr or None, d2_ptr or None, stream))
+
+    def bezier_check_device(self, params: InflateParams, polycoef, seg_time, orders, t_start, stop_time, dt, cap, pos_ptr, radius_ptr, d2_ptr,
+                            idx_ptr, first_hit_ptr, nsamples_ptr, stream: int = 0):
+        traj, keep = _traj(polycoef, seg_time, orders)
+        _chk(lib().pct_bezier_check_dev(self._h, C.byref(traj), C.byref(params), float(t_start), float(stop_time), float(dt), int(cap),
+                                        pos_ptr or None, radius_ptr, d2_ptr or None, idx_ptr or None, first_hit_ptr, nsamples_ptr, stream))
+        return keep                                     # host arrays the stream copies from: keep them alive until it has passed
 
     def radius_count_device(self, q_ptr: int, r_ptr: int, Q: int, cnt_ptr: int, stream: int = 0, algo: int = ALGO_AUTO):
         _chk(lib().pct_radius_count_batch_dev(self._h, algo, q_ptr, r_ptr, int(Q), cnt_ptr, stream))

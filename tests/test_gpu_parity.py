@@ -625,3 +625,56 @@ def test_four_million_query_batch(E, oracle):
     bi, bd = oracle.brute_nearest(pts, q[-32:])
     assert np.array_equal(dg[-32:], bd) and np.array_equal(ig[-32:].astype(np.int64), bi.astype(np.int64))
     c.close()
+
+
+@pytest.mark.parametrize("kind", ["none", "grid", "ring"])
+def test_stream_variants_of_inflate_and_bezier(E, kind):
+    """pct_inflate_batch_dev / pct_bezier_check_dev (device buffers, caller's stream) give exactly what the host-buffer entry points
+    give, on an un-indexed, a cell-sorted and a rolling-map cloud"""
+    import torch
+    g = load_golden("bezier_check.npz")
+    pts = g["points"]
+    c = E.Cloud(len(pts))
+    if kind == "ring":
+        c.ring_index()
+    c.set_input(pts)
+    if kind == "grid":
+        c.build_grid()
+    prm = E.inflate_params(g["start"], float(g["sample_range"]), float(g["search_margin"]), float(g["max_radius"]))
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    # inflation of 3000 planner points
+    p64 = (synth.uniform_points(314, 3000, float(pts.min()), float(pts.max())).astype(np.float64) + 1e-5)
+    want_r, want_i, want_d = c.inflate(prm, p64)
+    c.reserve_queries(4096)
+    d_p = torch.from_numpy(p64).to(dev)
+    d_r = torch.empty(3000, dtype=torch.float64, device=dev)
+    d_i = torch.empty(3000, dtype=torch.int32, device=dev)
+    d_d = torch.empty(3000, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    c.inflate_device(prm, d_p.data_ptr(), 3000, d_r.data_ptr(), d_i.data_ptr(), d_d.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(d_r.cpu().numpy(), want_r) and np.array_equal(d_d.cpu().numpy(), want_d)
+    assert np.array_equal(d_i.cpu().numpy().view(np.uint32), want_i)
+    # the sampled check of every fixture case
+    cap = 512
+    d_pos = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+    d_rad = torch.empty(cap, dtype=torch.float64, device=dev)
+    d_d2 = torch.empty(cap, dtype=torch.float64, device=dev)
+    d_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_fh = torch.empty(1, dtype=torch.int64, device=dev)
+    d_ns = torch.empty(1, dtype=torch.int32, device=dev)
+    for i in range(int(g["n_cases"])):
+        t0, stop = float(g[f"case{i}_t_start"]), float(g[f"case{i}_stop_time"])
+        want = c.bezier_check(prm, g[f"case{i}_polycoef"], g["seg_time"], g["orders"], t0, stop, cap=cap)
+        keep = c.bezier_check_device(prm, g[f"case{i}_polycoef"], g["seg_time"], g["orders"], t0, stop, 0.02, cap, d_pos.data_ptr(), d_rad.data_ptr(),
+                                     d_d2.data_ptr(), d_idx.data_ptr(), d_fh.data_ptr(), d_ns.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        del keep
+        n = int(d_ns.item())
+        assert n == want["n"] and int(d_fh.item()) == want["first_hit"] == int(g[f"case{i}_first_hit"])
+        m = min(n, cap)
+        np.testing.assert_allclose(d_pos.cpu().numpy()[:m], want["pos"], rtol=1e-12, atol=1e-12)
+        same = np.all(d_pos.cpu().numpy()[:m].astype(np.float32) == want["pos"].astype(np.float32), axis=1)
+        assert np.array_equal(d_rad.cpu().numpy()[:m][same], want["radius"][same]) and np.array_equal(d_d2.cpu().numpy()[:m][same], want["d2"][same])
+    c.close()

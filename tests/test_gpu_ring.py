@@ -352,3 +352,47 @@ def test_ring_index_randomised_appends(E, oracle):
             check_nn(E, c, m, q, oracle, f"cap {cap} ext {ext} {kind} n {n}")
             done += 1
         c.close()
+
+
+def test_replan_plan_randomised_shapes(E, oracle):
+    """randomised trajectories through ONE plan: 1-5 segments of order 1-12 with unequal segment times, start times inside later
+    segments, horizons from 0.1 s to beyond the trajectory, sampling steps 0.02 / 0.05 s, 0-64 corridor nodes, more samples than the
+    plan holds -- node / control-point results bit-exact, sample enumeration exact, sample radii exact wherever the narrowed position
+    is bit-identical to the oracle's (device pow vs libm pow)"""
+    rng = np.random.default_rng(77)
+    P = S.C5_PARAMS
+    pts = np.concatenate([S.c5_frame(k, 8_000, 0.7) for k in range(10)])
+    c = E.Cloud(len(pts))
+    c.ring_index()
+    c.set_input(pts)
+    plan = E.ReplanPlan(c, 64, 128, 5)
+    for it in range(60):
+        nseg = int(rng.integers(1, 6))
+        orders = rng.integers(1, 13, nseg).astype(np.int32)
+        T = rng.uniform(0.3, 2.0, nseg)
+        row = 3 * (int(orders.max()) + 1)
+        coef = np.zeros((nseg, row))
+        x = 0.0
+        for i in range(nseg):
+            m = int(orders[i]) + 1
+            for d in range(3):
+                base = [x + np.linspace(0, 3.0, m), np.zeros(m), np.full(m, 2.5)][d]
+                coef[i, d * m:(d + 1) * m] = (base + rng.uniform(-0.4, 0.4, m)) / T[i]
+            x += 3.0
+        t_start = float(rng.uniform(0, T.sum() * 1.1)) if rng.random() < 0.6 else 0.0
+        stop = float(rng.choice([0.1, 0.5, 2.0, 3.0, 10.0]))
+        dt = float(rng.choice([0.02, 0.05]))
+        nodes = (rng.uniform(-1, 1, (int(rng.integers(0, 65)), 3)) * [6.0, 3.0, 1.0] + [5.0, 0.0, 2.5])
+        start = (float(rng.uniform(-2, 2)), 0.0, 2.5)
+        prm = E.inflate_params(start, float(rng.choice([30.0, 6.0])), P["search_margin"], P["max_radius"])     # 6 m: the early-out fires for far points
+        want_nn = bool(rng.integers(0, 2))
+        got = plan.run(prm, nodes, coef, T, orders, t_start, stop, dt, want_nn=want_nn)
+        ref = oracle.replan_tick(pts, start, prm.sample_range, P["search_margin"], P["max_radius"], nodes, coef, T, orders, t_start, stop, dt, cap=128)
+        assert got["nsamples"] == ref["nsamples"] and got["nctrl"] == ref["nctrl"], it
+        n = min(ref["nsamples"], 128)
+        assert len(got["sample_radius"]) == n
+        same = compare_tick(E, got, ref, len(nodes), want_nn, f"case {it}")
+        if same.all():
+            assert got["first_hit_sample"] == ref["first_hit_sample"], it
+    plan.close()
+    c.close()
