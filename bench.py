@@ -213,6 +213,7 @@ def parse():
     ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming / brute-force / corridor probes (0 = skip)")
     ap.add_argument("--replan-probe", type=int, default=1, help="config C5: rolling 5M-point cloud, 20 Hz replan ticks (0 = skip)")
     ap.add_argument("--c4-probe", type=int, default=1, help="N = 1: also run the 100 M-point cloud (config C4) on this one card (0 = skip)")
+    ap.add_argument("--spatial-leg", type=int, default=1, help="N > 1: also time the batch with spatially routed queries (0 = skip)")
     ap.add_argument("--one-gpu-ref", type=int, default=1, help="N > 1: rank 0 also times the batch against the whole cloud on its one card (0 = skip)")
     return ap.parse_args()
 
@@ -386,6 +387,33 @@ def main():
                    "brute_force_ms_per_batch": brute_ms, "brute_force_pair_evals_per_s": 4096 * n_total / (brute_ms * 1e-3),
                    "brute_force_merged_answers_per_s": 4096 / (brute_ms * 1e-3),
                    "indexed_ms_per_batch": index_ms, "indexed_merged_answers_per_s": (4096 / (index_ms * 1e-3)) if index_ms else None}
+    # ---- N > 1: the same batch with spatially routed queries (slab ownership + halo, dist.SpatialShardedCloud): each rank answers
+    # only the queries of its slab, the same all_reduce(min) pair merges.  Secondary leg: a failure here must not cost the line.
+    spatial = None
+    if c4 and algo == E.ALGO_GRID and a.spatial_leg:
+        try:
+            sp = D.SpatialShardedCloud(rank, world, dev)
+            t1 = time.perf_counter()
+            sp.build(local_pts, sc.begin)
+            t_build = time.perf_counter() - t1
+            for _ in range(2):
+                sd2, sidx = sp.nn(q)
+            barrier()
+            t1 = time.perf_counter()
+            reps = max(3, a.steps // 2)
+            for _ in range(reps):
+                sd2, sidx = sp.nn(q)
+            barrier()
+            sp_ms = 1e3 * (time.perf_counter() - t1) / reps
+            spatial = {"what": "the same batch, queries routed to the rank that owns their slab (halo 4 point spacings, certified answers, second round "
+                               "for the rest); same all_reduce(min) exchange; un-pipelined",
+                       "ms_per_step": sp_ms, "merged_answers_per_s": Q / (sp_ms * 1e-3), "redistribution_s": round(t_build, 3),
+                       "slab_points_rank0": sp.slab_points, "owned_queries_rank0_per_batch": sp.stats["owned"] / max(sp.stats["batches"], 1),
+                       "uncertified_rank0_per_batch": sp.stats["uncertified"] / max(sp.stats["batches"], 1),
+                       "same_answers_as_index_range_shards": bool(torch.equal(sd2, d2_keep) and torch.equal(sidx.to(torch.int32), idx_keep.to(torch.int32)))}
+            sp.close()
+        except Exception as ex:      # noqa: BLE001  (report, do not fail the benchmark line)
+            spatial = {"error": f"{type(ex).__name__}: {ex}"}
     one_gpu = None
     if c4 and a.one_gpu_ref:
         # strong-scaling base in the same run: rank 0's card alone holds the WHOLE cloud and answers the same batch
@@ -468,6 +496,8 @@ def main():
     }
     if c4_legs:
         out["c4_q4096"] = c4_legs
+    if spatial:
+        out["spatial_routing"] = spatial
     if one_gpu:
         out["one_gpu_whole_cloud"] = dict(one_gpu, speedup_of_this_run=value / one_gpu["answers_per_s"])
 

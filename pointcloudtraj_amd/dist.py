@@ -222,3 +222,185 @@ class ShardedCloud:
 
     def close(self):
         self.cloud.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Spatial ownership of queries.  Index-range shards make every rank answer every query, which scales the
+# brute-force kernels (per-rank work = Q x N/W pairs) but not the cell-pruned one (a query costs ~49 scanned points whatever the
+# shard's size).  Here the cloud is re-distributed once into W slabs along its longest axis (equal point counts, a halo of a few
+# point spacings on both sides), the replicated query batch is split by slab, each rank answers only the queries whose slab it
+# owns, and the SAME exchange step (all_reduce(min) on d2, all_reduce(min) on the matching global indices) delivers the merged
+# answer -- non-owners simply offer +inf.  An answer is certified when the point found is closer than the edge of the owner's halo;
+# the rare uncertified query is flagged through the distance reduction itself (the owner offers -1) and answered by everybody in
+# a second, small round.  Results are identical to the single-cloud answer (lowest global index on exact ties: points are kept
+# in ascending global-index order inside a slab, and the index reduction takes the minimum across slabs).
+# ---------------------------------------------------------------------------------------------------------------------------
+class _EngineSearcher:
+    """local search on this rank's slab through libpct_engine.so (cell-pruned kernel)"""
+
+    def __init__(self, device_index: int):
+        from . import engine as E
+        self.E = E
+        torch.cuda.set_device(device_index)
+        E.init(device_index)
+        self.device = torch.device("cuda", device_index)
+        self.cloud = None
+
+    def load(self, pts: np.ndarray):
+        if self.cloud is not None:
+            self.cloud.close()
+        self.cloud = self.E.Cloud(max(len(pts), 1))
+        self.cloud.set_input(pts)
+        if len(pts):
+            self.cloud.build_grid()
+        self._cap = 0
+
+    def search(self, q: torch.Tensor):
+        """q: float32 [m,3] on self.device -> (local idx int64 [m], d2 float64 [m]) on the same device"""
+        m = q.shape[0]
+        if m > self._cap:
+            self.cloud.reserve_queries(m)
+            self._idx = torch.empty(m, dtype=torch.int32, device=self.device)
+            self._d2 = torch.empty(m, dtype=torch.float64, device=self.device)
+            self._cap = m
+        if m:
+            self.cloud.nn_device(q.data_ptr(), m, self._idx.data_ptr(), self._d2.data_ptr(), torch.cuda.current_stream().cuda_stream, 0)
+        return self._idx[:m].to(torch.int64) & 0xFFFFFFFF, self._d2[:m]
+
+    def close(self):
+        if self.cloud is not None:
+            self.cloud.close()
+
+
+class SpatialShardedCloud:
+    """Slab-owned shards with routed queries.  `searcher`: object with load(points float32 [n,3]), search(q) -> (local idx, d2) and
+    a `device` attribute (default: the engine on `device_index`; the CPU tests plug the oracle in)."""
+
+    def __init__(self, rank: int, world: int, device_index: int = 0, group=None, searcher=None, halo_spacings: float = 4.0):
+        self.rank, self.world, self.group = rank, world, group
+        self.searcher = searcher if searcher is not None else _EngineSearcher(device_index)
+        self.device = self.searcher.device
+        self.halo_spacings = float(halo_spacings)
+        self.stats = {"owned": 0, "uncertified": 0, "batches": 0}
+
+    def _ar(self, t: torch.Tensor, op):
+        s = _staging(t, self.group)
+        dist.all_reduce(s, op=op, group=self.group)
+        return s.to(t.device) if s is not t else t
+
+    def build(self, local_points: np.ndarray, index_begin: int):
+        """local_points: this rank's rows [index_begin, index_begin + n) of the global cloud (float32 [n,3]).  Collective."""
+        W = self.world
+        pts = np.ascontiguousarray(local_points, np.float32).reshape(-1, 3)
+        n = len(pts)
+        # collectives run on device tensors over RCCL, on host tensors over gloo
+        cdev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        # global bounding box and point count
+        lo = torch.from_numpy(pts.min(0).astype(np.float64) if n else np.full(3, np.inf)).to(cdev)
+        hi = torch.from_numpy(pts.max(0).astype(np.float64) if n else np.full(3, -np.inf)).to(cdev)
+        cnt = torch.tensor([float(n)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+        self.n_total = int(cnt.item())
+        if self.n_total == 0:
+            self.axis, self.cuts, self.halo = 0, np.zeros(W + 1), 0.0
+            self.searcher.load(np.zeros((0, 3), np.float32))
+            self.gidx = torch.zeros(0, dtype=torch.int64, device=self.device)
+            return
+        lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+        ext = np.maximum(hi - lo, 1e-30)
+        self.axis = int(np.argmax(ext))
+        a = self.axis
+        # equal-count cuts along the axis from a global histogram
+        nb = 4096
+        if n:
+            h = torch.from_numpy(np.histogram(pts[:, a].astype(np.float64), bins=nb, range=(lo[a], hi[a] + ext[a] * 1e-9))[0].astype(np.float64))
+        else:
+            h = torch.zeros(nb, dtype=torch.float64)
+        h = h.to(cdev)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        cum = np.cumsum(h.cpu().numpy())
+        edges = np.linspace(lo[a], hi[a] + ext[a] * 1e-9, nb + 1)
+        cuts = [-np.inf]
+        for k in range(1, W):
+            cuts.append(float(edges[min(int(np.searchsorted(cum, self.n_total * k / W)) + 1, nb)]))
+        cuts.append(np.inf)
+        self.cuts = np.asarray(cuts)
+        spacing = float(np.cbrt(np.prod(np.maximum(ext, ext.max() * 1e-3)) / self.n_total))
+        self.halo = self.halo_spacings * spacing
+        # every point goes to its owner slab and to every slab whose halo it falls into
+        x = pts[:, a].astype(np.float64)
+        gid = index_begin + np.arange(n, dtype=np.int64)
+        send_pts, send_gid = [], []
+        for k in range(W):
+            m = (x >= self.cuts[k] - self.halo) & (x < self.cuts[k + 1] + self.halo)
+            send_pts.append(pts[m])
+            send_gid.append(gid[m])
+        counts = torch.tensor([len(g) for g in send_gid], dtype=torch.int64, device=cdev)
+        recv_counts = torch.zeros(W, dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)
+        sp = torch.from_numpy(np.concatenate(send_pts).astype(np.float32).reshape(-1, 3)).to(cdev)
+        sg = torch.from_numpy(np.concatenate(send_gid)).to(cdev)
+        ins, outs = counts.cpu().tolist(), recv_counts.cpu().tolist()
+        rp = torch.empty((sum(outs), 3), dtype=torch.float32, device=cdev)
+        rg = torch.empty(sum(outs), dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(rp, sp, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
+        dist.all_to_all_single(rg, sg, output_split_sizes=outs, input_split_sizes=ins, group=self.group)
+        order = torch.argsort(rg, stable=True)                   # ascending global index: "lowest local index" = "lowest global index"
+        self.searcher.load(rp[order].cpu().numpy())
+        self.gidx = rg[order].to(self.device)
+        self.slab_points = int(rg.numel())
+
+    def _owner_of(self, q: torch.Tensor) -> torch.Tensor:
+        cuts = torch.as_tensor(self.cuts[1:-1], dtype=torch.float64, device=q.device)
+        return torch.bucketize(q[:, self.axis].to(torch.float64), cuts, right=True)
+
+    def nn(self, q: torch.Tensor):
+        """q: float32 [Q,3] on self.device, the same on every rank.  Returns (d2 float64 [Q], idx int64 [Q], -1 = empty cloud) on every rank."""
+        Q = q.shape[0]
+        dev = q.device
+        inf = float("inf")
+        d2 = torch.full((Q,), inf, dtype=torch.float64, device=dev)
+        gi = torch.full((Q,), _I64_MAX, dtype=torch.int64, device=dev)
+        if self.n_total == 0:
+            return d2, torch.full((Q,), -1, dtype=torch.int64, device=dev)
+        mine = torch.nonzero(self._owner_of(q) == self.rank).squeeze(1)
+        if mine.numel() and self.gidx.numel():
+            li, ld = self.searcher.search(q[mine].contiguous())
+            valid = torch.isfinite(ld)
+            g = torch.where(valid, self.gidx[torch.where(valid, li, torch.zeros_like(li))], torch.full_like(li, _I64_MAX))
+            # certified: nothing outside this slab's halo can be nearer than what was found
+            x = q[mine, self.axis].to(torch.float64)
+            lo_edge, hi_edge = self.cuts[self.rank] - self.halo, self.cuts[self.rank + 1] + self.halo
+            margin = torch.minimum(x - lo_edge if np.isfinite(lo_edge) else torch.full_like(x, inf),
+                                   hi_edge - x if np.isfinite(hi_edge) else torch.full_like(x, inf))
+            cert = valid & (margin > 0) & (ld <= margin * margin)
+            d2[mine] = torch.where(cert, ld, torch.full_like(ld, -1.0))     # -1 = "ask everybody": it wins the min-reduction
+            gi[mine] = torch.where(cert, g, torch.full_like(g, _I64_MAX))
+            self.stats["owned"] += int(mine.numel())
+            self.stats["uncertified"] += int((~cert).sum().item())
+        elif mine.numel():
+            d2[mine] = -1.0                                      # an owner without points: everybody answers
+        self.stats["batches"] += 1
+        best = self._ar(d2.clone(), dist.ReduceOp.MIN)
+        cand = torch.where((d2 == best) & torch.isfinite(d2) & (d2 >= 0), gi, torch.full_like(gi, _I64_MAX))
+        cand = self._ar(cand, dist.ReduceOp.MIN)
+        flagged = torch.nonzero(best < 0).squeeze(1)             # the same set on every rank (derived from reduced data)
+        if flagged.numel():
+            fd = torch.full((flagged.numel(),), inf, dtype=torch.float64, device=dev)
+            fg = torch.full((flagged.numel(),), _I64_MAX, dtype=torch.int64, device=dev)
+            if self.gidx.numel():
+                li, ld = self.searcher.search(q[flagged].contiguous())
+                valid = torch.isfinite(ld)
+                fd = torch.where(valid, ld, fd)
+                fg = torch.where(valid, self.gidx[torch.where(valid, li, torch.zeros_like(li))], fg)
+            fbest = self._ar(fd.clone(), dist.ReduceOp.MIN)
+            fcand = self._ar(torch.where((fd == fbest) & torch.isfinite(fd), fg, torch.full_like(fg, _I64_MAX)), dist.ReduceOp.MIN)
+            best[flagged] = fbest
+            cand[flagged] = fcand
+        return best, torch.where(cand == _I64_MAX, torch.full_like(cand, -1), cand)
+
+    def close(self):
+        if hasattr(self.searcher, "close"):
+            self.searcher.close()

@@ -86,3 +86,76 @@ def test_shard_ranges_partition_the_cloud():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
+class _OracleSearcher:
+    """stands in for the per-slab HIP kernel on CPU: exhaustive fp64 scan, lowest local index on ties"""
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+
+    def load(self, pts):
+        self.pts = np.ascontiguousarray(pts, np.float32)
+
+    def search(self, q):
+        from oracle import oracle as O
+        m = q.shape[0]
+        if m == 0 or len(self.pts) == 0:
+            return torch.zeros(m, dtype=torch.int64), torch.full((m,), float("inf"), dtype=torch.float64)
+        i, d = O.brute_nearest(self.pts, q.numpy())
+        return torch.from_numpy(i.astype(np.int64)), torch.from_numpy(d.copy())
+
+
+def _spatial_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from pointcloudtraj_amd import synth
+    from pointcloudtraj_amd.dist import SpatialShardedCloud, shard_range
+    if case == "uniform":
+        pts = synth.uniform_points(17, 30_000, 0, 50)
+        halo = 4.0
+    elif case == "thin_halo":      # a halo far thinner than the point spacing: most boundary queries must take the second round
+        pts = synth.uniform_points(18, 4_000, 0, 50)
+        halo = 0.05
+    elif case == "ties":           # grid-aligned points, every one duplicated at the far end of the index range
+        base = synth.clustered_points(8, 3_000, 0, 20)
+        pts = np.concatenate([base, base])
+        halo = 2.0
+    else:                          # two points in all: most slabs are empty
+        pts = synth.uniform_points(19, 2, 0, 50)
+        halo = 4.0
+    q = np.concatenate([synth.uniform_points(9, 600, -5, 55), pts[:40], synth.uniform_points(10, 20, -400, 400)])
+    b, e = shard_range(len(pts), rank, world)
+    sc = SpatialShardedCloud(rank, world, searcher=_OracleSearcher(), halo_spacings=halo)
+    sc.build(pts[b:e], b)
+    d2, idx = sc.nn(torch.from_numpy(q))
+    d2b, idxb = sc.nn(torch.from_numpy(q[::-1].copy()))          # a second batch through the same shards
+    own = torch.tensor([float(sc.stats["owned"]), float(sc.stats["uncertified"])], dtype=torch.float64)
+    dist.all_reduce(own)
+    if rank == 0:
+        wi, wd = O.brute_nearest(pts, q)
+        ok = bool(np.array_equal(d2.numpy(), wd) and np.array_equal(idx.numpy(), wi.astype(np.int64)) and
+                  np.array_equal(d2b.numpy(), wd[::-1]) and np.array_equal(idxb.numpy(), wi[::-1].astype(np.int64)))
+        ok = ok and int(own[0].item()) == 2 * len(q)             # every query had exactly one owner
+        if case == "uniform":
+            ok = ok and own[1].item() < 0.1 * own[0].item()      # a 4-spacing halo certifies nearly everything in the first round
+        if case == "thin_halo":
+            ok = ok and own[1].item() > 0                         # ... and a thin one exercises the second round
+        with open(os.path.join(out_dir, f"ok_spatial_{case}_{world}"), "w") as f:
+            f.write("1" if ok else f"0 owned {own.tolist()}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,case", [(2, "uniform"), (3, "uniform"), (3, "thin_halo"), (2, "ties"), (3, "tiny")])
+def test_spatially_routed_queries_equal_single_cloud(tmp_path, world, case):
+    """SpatialShardedCloud (slab ownership + halo + certified answers + second round): merged answers must equal the single-cloud
+    answer bit for bit, each query answered by exactly one owner in the first round"""
+    from oracle import oracle as O
+    O.build()
+    port = _free_port()
+    mp.spawn(_spatial_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert open(tmp_path / f"ok_spatial_{case}_{world}").read() == "1"

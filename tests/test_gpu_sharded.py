@@ -115,6 +115,10 @@ def test_bench_two_ranks_on_one_card():
     assert abs(d["config"]["query_shard_evaluations_per_s"] - 2 * d["value"]) < 1e-6 * d["value"]
     assert d["one_gpu_whole_cloud"]["same_answers_as_sharded"] is True
     assert d["c4_q4096"]["brute_force_ms_per_batch"] > 0
+    sp = d["spatial_routing"]                              # slab-owned queries through the HIP kernels, same answers, each rank ~half the batch
+    assert "error" not in sp, sp
+    assert sp["same_answers_as_index_range_shards"] is True
+    assert 0.3 * 65536 < sp["owned_queries_rank0_per_batch"] < 0.7 * 65536 and sp["uncertified_rank0_per_batch"] < 0.02 * 65536
 
 
 def test_cpp_shard_client_over_rccl():
