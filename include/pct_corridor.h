@@ -43,6 +43,9 @@ int pct_corridor_speculation_stats(pct_corridor *c, uint64_t *replayed_from_batc
  * off: the same three stages as three batched launches.  The corridor does not depend on it. */
 int pct_corridor_set_fused_expansion(pct_corridor *c, int on);
 int pct_corridor_expansion_launches(pct_corridor *c, uint64_t *launches);
+/* GPU round trips treeRepair (corridor_finder.cpp:938-1021) has made: two per pass -- one launch for every failed node's neighbourhood,
+ * one for the sphere inflation of every node that may be re-checked -- where the reference's loop asks two per neighbour */
+int pct_corridor_repair_batches(pct_corridor *c, uint64_t *batches);
 
 #ifdef __cplusplus
 }

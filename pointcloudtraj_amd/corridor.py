@@ -32,6 +32,7 @@ def lib():
         L.pct_corridor_speculation_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_corridor_set_fused_expansion.argtypes = [vp, C.c_int]
         L.pct_corridor_expansion_launches.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.pct_corridor_repair_batches.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.pct_corridor_set_input.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int]
         L.pct_corridor_set_pt.argtypes = [vp, d3, d3] + [C.c_double] * 7 + [C.c_int, C.c_double, C.c_double]
         L.pct_corridor_set_start_pt.argtypes = [vp, d3, d3]
@@ -82,6 +83,11 @@ class SafeRegionRrtStar:
     def expansionLaunches(self) -> int:
         n = C.c_uint64()
         self._chk(self.L.pct_corridor_expansion_launches(self.h, C.byref(n)))
+        return n.value
+
+    def repairBatches(self) -> int:
+        n = C.c_uint64()
+        self._chk(self.L.pct_corridor_repair_batches(self.h, C.byref(n)))
         return n.value
 
     def speculationStats(self):

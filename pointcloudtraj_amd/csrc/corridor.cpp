@@ -58,6 +58,10 @@ int pct_corridor_expansion_launches(pct_corridor *c, uint64_t *launches)
 {
     return guarded([&] { if (launches) *launches = c->impl->expansionLaunches(); });
 }
+int pct_corridor_repair_batches(pct_corridor *c, uint64_t *batches)
+{
+    return guarded([&] { if (batches) *batches = c->impl->repairBatches(); });
+}
 int pct_corridor_set_input(pct_corridor *c, const void *points, int64_t n, int64_t stride_bytes, int build_index)
 {
     return guarded([&] { c->impl->setInput(points, n, stride_bytes, build_index != 0); });

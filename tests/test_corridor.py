@@ -68,3 +68,7 @@ def test_gpu_corridor_matches_oracle(oracle, speculation, fused):
             assert np.array_equal(rw, rg), f"phase {k}: corridor radii differ"
             assert sw["inflation_queries"] == sg["inflation_queries"]
         assert want[0][2]["path_exists"]
+        if cloud2 is not None:
+            # the drastically different second frame invalidates corridor nodes: SafeRegionEvaluate hands them to treeRepair, which now
+            # makes two GPU round trips per pass whatever the number of neighbours (it used to make two per neighbour)
+            assert 0 < finder.repairBatches() <= 8, finder.repairBatches()
