@@ -453,7 +453,9 @@ bool lds_sort_on()
 }
 
 // counting sort of the batch by coarse cell -> c->d_perm (nullptr result = keep arrival order)
-int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const uint32_t **perm_out)
+// need_perm / need_inv: the 8-lanes-per-query kernels read the sorted records only; the lane-per-query kernels read perm, the
+// sorted-result gather reads inv -- 4 B per query of scattered (perm) or streamed (inv) writes that the default path does not pay
+int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const uint32_t **perm_out, bool need_perm = true, bool need_inv = false)
 {
     *perm_out = nullptr;
     int64_t min_q = 16384;
@@ -493,12 +495,14 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         qsort_hist_kernel<<<ceil_div(Q, (int64_t)hist_per_block), 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, hist_per_block, keys, total1, fill1,
                                                                               pingpong ? total1_next : nullptr);
         if (levels == 1) {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, c->d_perm, c->d_inv);
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, need_perm ? c->d_perm : nullptr,
+                                                      need_inv ? c->d_inv : nullptr, 1);
             if (pingpong) c->sort_phase ^= 1;
             else HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));   // the fine pass would have re-zeroed it
         } else {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr, nullptr);
-            qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, c->d_perm, c->d_qsorted, c->d_inv);
+            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr, nullptr, 0);
+            qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, need_perm ? c->d_perm : nullptr,
+                                                                    c->d_qsorted, need_inv ? c->d_inv : nullptr);
         }
         HIPCHK(hipGetLastError());
         *perm_out = c->d_perm;
@@ -747,8 +751,9 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters) * kWorkSlots, s));
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
-        PCTCHK(bin_queries(c, d_q, Q, s, &perm));
         static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
+        static const bool sorted_writes_on = [] { const char *e = std::getenv("PCT_SORTED_WRITES"); return e ? std::atoi(e) != 0 : false; }();
+        PCTCHK(bin_queries(c, d_q, Q, s, &perm, !coop, coop && sorted_writes_on));
         dom_begin(c, s);
         if (coop) {   // 8 lanes per query (default)
             const int blocks = ceil_div(Q, 256 / kCoop);
@@ -804,8 +809,8 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
         if (c->count_work) HIPCHK(hipMemsetAsync(c->d_work, 0, sizeof(WorkCounters) * kWorkSlots, s));
         begin_timing(c, s);
         const uint32_t *perm = nullptr;
-        PCTCHK(bin_queries(c, d_q, Q, s, &perm));
         static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
+        PCTCHK(bin_queries(c, d_q, Q, s, &perm, !coop, false));
         dom_begin(c, s);
         if (coop) {   // 8 lanes per query (default)
             const int blocks = ceil_div(Q, 256 / kCoop);

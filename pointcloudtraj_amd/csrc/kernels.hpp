@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDes
                                                               uint32_t Q, uint32_t per_block, int lshift, const uint32_t *__restrict__ total1,
                                                               uint32_t *__restrict__ fill1, uint32_t *__restrict__ start1,
                                                               uint32_t *__restrict__ tmp_key, float4 *__restrict__ tmp_rec,
-                                                              uint32_t *__restrict__ perm, uint32_t *__restrict__ inv)
+                                                              uint32_t *__restrict__ perm, uint32_t *__restrict__ inv, int final_level)
 {
     static_assert(kSortBuckets == 1024, "one thread per bucket");
     __shared__ uint32_t h[kSortBuckets];
@@ -1115,8 +1115,8 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDes
         if (key[k] != 0xFFFFFFFFu) {
             const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
             const uint32_t pos = basepos[key[k] >> lshift] + atomicAdd(&h[key[k] >> lshift], 1u);
-            if (perm) perm[pos] = t;                  // single-level mode: this IS the final order
-            else tmp_key[pos] = key[k];
+            if (!final_level) tmp_key[pos] = key[k];  // a fine pass follows and needs the key
+            else if (perm) perm[pos] = t;             // single-level mode: this IS the final order; perm only for the kernels that read it
             if (inv) inv[t] = pos;                    // where query t went (coalesced): results come back through it
             tmp_rec[pos] = make_float4(qv[k][0], qv[k][1], qv[k][2], __uint_as_float(t));
         }
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(kFineThreads) void qsort_fine_kernel(const uint32_t
     for (uint32_t i = s + threadIdx.x; i < e; i += kFineThreads) {
         const float4 rec = tmp_rec[i];
         const uint32_t pos = s + atomicAdd(&h[tmp_key[i] & lmask], 1u);
-        perm[pos] = __float_as_uint(rec.w);
+        if (perm) perm[pos] = __float_as_uint(rec.w);
         qsorted[pos] = rec;
         if (inv) inv[__float_as_uint(rec.w)] = pos;
     }
