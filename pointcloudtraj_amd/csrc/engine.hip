@@ -1667,9 +1667,13 @@ int pct_rrt_expand_batch(pct_cloud *nodes, pct_cloud *obstacles, const pct_infla
     const double reach = p->max_radius + p->search_margin;       // only the radius is wanted: stop once everything unseen is beyond it
     rrt_expand_kernel<<<(int)K, 256, 0, g_stream>>>(nodes->x, nodes->y, nodes->z, (uint32_t)nodes->count, nodes->d_aux, nodes->d_xin,
                                                     obstacles->G, obstacles->sorted, obstacles->cell_start, obstacles->C,
-                                                    obstacles->count == 0 ? 1 : 0, to_dev(p), reach * reach, nodes->d_xids, cap, nodes->d_eout, next_signal(nodes));
+                                                    obstacles->count == 0 ? 1 : 0, to_dev(p), reach * reach, nodes->d_xids, cap, nodes->d_eout,
+                                                    K <= 8 ? next_signal(nodes) : ExpressSignal{});
     HIPCHK(hipGetLastError());
-    PCTCHK(express_wait(nodes));
+    // one or a few samples: the completion word (1500 one-sample iterations 37 -> 32 ms); speculative batches of 16-256 blocks:
+    // a system-scope fence per block costs more than the stream synchronise saves (2.85 vs 2.60 ms per 1500 iterations at K = 64)
+    if (K <= 8) PCTCHK(express_wait(nodes));
+    else HIPCHK(hipStreamSynchronize(g_stream));
     for (int64_t k = 0; k < K; k++) {
         const ExpandOut &e = nodes->h_eout[k];
         out[k].center[0] = e.cx; out[k].center[1] = e.cy; out[k].center[2] = e.cz;

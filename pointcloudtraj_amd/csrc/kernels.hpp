@@ -2110,6 +2110,7 @@ __global__ __launch_bounds__(256) void rrt_expand_kernel(const float *__restrict
     __shared__ double s_d[4];
     __shared__ uint32_t s_i[4];
     __shared__ uint32_t s_n;
+    __shared__ uint32_t s_ids[256];                // the neighbourhood is gathered here and handed to the host by ONE wave (below)
     const uint32_t slot = blockIdx.x;
     const double sx = samples[3 * slot], sy = samples[3 * slot + 1], sz = samples[3 * slot + 2];
     if (threadIdx.x == 0) s_n = 0;
@@ -2159,16 +2160,33 @@ __global__ __launch_bounds__(256) void rrt_expand_kernel(const float *__restrict
         for (uint32_t i = threadIdx.x; i < n_nodes; i += 256)
             if (dist2((double)nx[i], (double)ny[i], (double)nz[i], qx, qy, qz) <= r2) {
                 const uint32_t pos = atomicAdd(&s_n, 1u);
-                if (pos < cap_per_query) ids[(size_t)slot * cap_per_query + pos] = i;
+                if (pos < 256u) s_ids[pos] = i;
+                else if (pos < cap_per_query) ids[(size_t)slot * cap_per_query + pos] = i;     // a neighbourhood beyond 256 nodes: straight to the host
             }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        out[slot].cx = cx; out[slot].cy = cy; out[slot].cz = cz; out[slot].radius = radius;
-        out[slot].near_idx = near;
-        out[slot].count = s_n;
+    const uint32_t n_hits = s_n;
+    if (n_hits > 256u) {                           // rare: many threads stored host-visible data, all of them fence
+        for (uint32_t k = threadIdx.x; k < min(256u, cap_per_query); k += 256) ids[(size_t)slot * cap_per_query + k] = s_ids[k];
+        if (threadIdx.x == 0) {
+            out[slot].cx = cx; out[slot].cy = cy; out[slot].cz = cz; out[slot].radius = radius;
+            out[slot].near_idx = near;
+            out[slot].count = n_hits;
+        }
+        express_done_block(sig);
+        return;
     }
-    express_done_block(sig);
+    // the usual case: wave 0 alone writes everything the host reads, so one wave fences instead of four
+    if (threadIdx.x < 64) {
+        for (uint32_t k = threadIdx.x; k < min(n_hits, cap_per_query); k += 64) ids[(size_t)slot * cap_per_query + k] = s_ids[k];
+        if (threadIdx.x == 0) {
+            out[slot].cx = cx; out[slot].cy = cy; out[slot].cz = cz; out[slot].radius = radius;
+            out[slot].near_idx = near;
+            out[slot].count = n_hits;
+        }
+        if (sig.seq) __threadfence_system();         // the wave's stores (ids by up to 64 lanes) before lane 0 takes the ticket
+        if (threadIdx.x == 0) express_done(sig);
+    }
 }
 
 constexpr int kMaxBezierOrder = 12;
