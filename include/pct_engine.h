@@ -16,6 +16,13 @@
  *                           (+ checkRadius :656-659, checkTrajPtCol :412-416), batched over the loops at
  *                           :829-835 (SafeRegionEvaluate) and :958-974 (treeRepair)
  *   pct_bezier_check        checkSafeTrajectory/getPosFromBezier  Planner/src/sim_planning_demo.cpp:715-781
+ *   pct_cloud_ring_index +  the per-frame rebuild of the search tree: rcvPointCloudCallBack -> setInput
+ *   pct_cloud_append_aos    Planner/src/sim_planning_demo.cpp:159-167 -> Planner/src/corridor_finder.cpp:93-99 (rolling map, config C5)
+ *   pct_ctrl_points_check   the containment the optimizer enforces on the control points, Planner/src/traj_optimizer.cpp:624-648,
+ *                           as the threshold test of checkTrajPtCol (corridor_finder.cpp:412-416) on control point * T_i
+ *   pct_plan_create_replan  one replan tick's query side in one captured graph: SafeRegionEvaluate's re-check loop
+ *   pct_plan_replan_run     corridor_finder.cpp:829-835 + checkSafeTrajectory sim_planning_demo.cpp:729-781 + the control points
+ *   pct_*_dev               the same batches on device buffers and the caller's stream (multi-GPU: include/pct_shard.h)
  *
  * Arithmetic contract (what "parity" means): coordinates are fp32 in HBM; every distance is
  * computed in fp64 from the float-widened operands as ((dx*dx + dy*dy) + dz*dz) with one
