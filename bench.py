@@ -238,9 +238,25 @@ def self_launch(a) -> int:
         child = os.environ.get("PCT_BENCH_CHILD") or os.path.abspath(__file__)      # test hook: a stand-in rank program (tests/test_bench_launch.py)
         procs.append(subprocess.Popen([sys.executable, child, *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+    # read rank 0's line while watching every rank: one that fails takes the others down with it (they would otherwise sit in a
+    # collective until its timeout) -- by their exact PIDs
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
     rcs = [p.wait() for p in procs]
-    if any(rcs):
+    reader.join(timeout=10)
+    out0 = buf[0] if buf else b""
+    if failed or any(rcs):
         sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
         return 1
     lines = [ln for ln in out0.decode(errors="replace").splitlines() if ln.startswith("{")]

@@ -1,5 +1,5 @@
 """Stand-in for one rank of bench.py (tests/test_bench_launch.py): joins the gloo group the launcher described in the environment,
-takes part in one all_reduce and, on rank 0, prints a bench-shaped JSON line.  FAKE_FAIL_RANK=R in the environment makes rank R exit non-zero."""
+takes part in one all_reduce and, on rank 0, prints a bench-shaped JSON line.  FAKE_FAIL_RANK=R in the environment makes rank R exit non-zero at the end, FAKE_DIE_EARLY_RANK=R before the rendezvous."""
 import argparse
 import json
 import os
@@ -14,6 +14,8 @@ ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--warmup", type=int, default=0)
 a, _ = ap.parse_known_args()
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+if rank == int(os.environ.get("FAKE_DIE_EARLY_RANK", "-1")):      # dies before it ever joins the group: the others would wait in the rendezvous
+    sys.exit(4)
 assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank and world == a.gpus
 dist.init_process_group("gloo", rank=rank, world_size=world)
 t = torch.tensor([float(rank + 1)], dtype=torch.float64)

@@ -10,11 +10,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, fail_rank=None):
+def _run(extra, fail_rank=None, die_early=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["PCT_BENCH_CHILD"] = os.path.join(ROOT, "tests", "helpers", "fake_rank.py")
     if fail_rank is not None:
         env["FAKE_FAIL_RANK"] = str(fail_rank)
+    if die_early is not None:
+        env["FAKE_DIE_EARLY_RANK"] = str(die_early)
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", *extra],
                           env=env, capture_output=True, text=True, timeout=300)
 
@@ -32,3 +34,12 @@ def test_self_launch_propagates_a_failing_rank():
     r = _run([], fail_rank=1)
     assert r.returncode != 0
     assert "exit codes" in r.stderr
+
+
+def test_self_launch_does_not_hang_when_a_rank_dies_before_the_rendezvous():
+    """rank 1 exits at once; rank 0 would wait for it in the rendezvous (default timeout: half an hour) -- the launcher must end it"""
+    import time
+    t0 = time.time()
+    r = _run([], die_early=1)
+    assert r.returncode != 0 and "exit codes" in r.stderr
+    assert time.time() - t0 < 120
