@@ -285,6 +285,12 @@ int pct_set_timing(pct_cloud *c, int level);
 /* dominant-kernel durations of the most recent batches (up to 64 are kept, oldest first): K batches can be queued back to
  * back without a host sync and every launch's duration read afterwards */
 int pct_kernel_ms_history(pct_cloud *c, float *ms, int cap, int *n);
+/* Sampling: with stride n > 1 the index path (PCT_ALGO_GRID batches) times only every n-th launch, the first one after this call
+ * included -- the kernel's own begin / end timestamps (hipExtLaunchKernel), no marker packets on the stream; timing every launch
+ * costs ~4 us of a 160 us step.  pct_kernel_ms_samples: how many durations have been recorded so far (host counter, no sync), so
+ * that a caller can tell how many of them fall into a region it brackets. */
+int pct_set_timing_stride(pct_cloud *c, int stride);
+int pct_kernel_ms_samples(pct_cloud *c, uint64_t *count);
 /* algorithmic work of the last batch: points examined (sum over queries), cells examined */
 int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanned);
 int pct_set_work_counters(pct_cloud *c, int enabled);

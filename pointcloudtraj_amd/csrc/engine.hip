@@ -9,6 +9,7 @@
 //   cell_start[ncells + 1]      u32 exclusive prefix of per-cell counts                   (grid only)
 //   query workspaces sized by pct_cloud_reserve_queries
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -170,6 +171,9 @@ struct pct_cloud {
     static constexpr int kDomRing = 64;
     hipEvent_t dom_ring[2 * kDomRing] = {};
     uint64_t dom_seq = 0;                       // completed (begin + end) pairs
+    uint64_t dom_launch = 0;                    // launches of the sampled (index) path since pct_set_timing_stride
+    int dom_stride = 1;                         // the index path records every dom_stride-th launch (pct_set_timing_stride)
+    hipEvent_t last2 = nullptr, last3 = nullptr;    // the most recent COMPLETE pair (pct_last_kernel_ms)
     bool ev_valid = false, dom_valid = false;
     int timing_level = 1;                       // 0 = no events, 1 = dominant kernel only (default), 2 = + the whole batch
     WorkCounters *d_work = nullptr;
@@ -393,21 +397,39 @@ void end_timing(pct_cloud *c, hipStream_t s)
 }
 
 // events around the dominant kernel of the batch (what rocprofv3's per-kernel average also measures)
-void dom_begin(pct_cloud *c, hipStream_t s)
+bool dom_ext_on()
+{
+    static const bool on = [] { const char *e = std::getenv("PCT_DOM_EXT_EVENTS"); return e ? std::atoi(e) != 0 : true; }();
+    return on;
+}
+
+// ext = the caller launches the kernel with hipExtLaunchKernelGGL(start = ev2, stop = ev3) itself (and calls dom_done): nothing is
+// recorded here; that path also honours the sampling stride
+void dom_begin(pct_cloud *c, hipStream_t s, bool ext = false)
 {
     c->dom_valid = false;
     if (c->capturing || c->timing_level < 1) return;
+    if (ext && c->dom_stride > 1 && (c->dom_launch++ % (uint64_t)c->dom_stride) != 0) return;
     const int slot = (int)(c->dom_seq % pct_cloud::kDomRing);
     c->ev2 = c->dom_ring[2 * slot];
     c->ev3 = c->dom_ring[2 * slot + 1];
+    if (ext && dom_ext_on()) { c->dom_valid = true; return; }
     if (hipEventRecord(c->ev2, s) == hipSuccess) c->dom_valid = true;
+}
+
+void dom_done(pct_cloud *c)
+{
+    c->dom_valid = false;
+    c->dom_seq++;
+    c->last2 = c->ev2;
+    c->last3 = c->ev3;
 }
 
 void dom_end(pct_cloud *c, hipStream_t s)
 {
     if (c->capturing || !c->dom_valid) return;
     if (hipEventRecord(c->ev3, s) != hipSuccess) c->dom_valid = false;
-    else c->dom_seq++;
+    else dom_done(c);
 }
 
 // streaming NN over the fp64 queries already in c->d_q64: one slice of at most c->part_q queries starting at qoff
@@ -754,7 +776,7 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
         static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
         static const bool sorted_writes_on = [] { const char *e = std::getenv("PCT_SORTED_WRITES"); return e ? std::atoi(e) != 0 : false; }();
         PCTCHK(bin_queries(c, d_q, Q, s, &perm, !coop, coop && sorted_writes_on));
-        dom_begin(c, s);
+        dom_begin(c, s, coop && !c->count_work);
         if (coop) {   // 8 lanes per query (default)
             const int blocks = ceil_div(Q, 256 / kCoop);
             // sorted batches: the kernel writes its results in sorted order (full lines) and one gather pass puts them back into
@@ -766,7 +788,13 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
             if (c->count_work)
                 nn_grid_coop_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
                                                                   perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
-            else
+            else if (c->dom_valid && dom_ext_on()) {
+                // the kernel's own begin / end timestamps (hipExtLaunchKernel): no marker packets on the stream -- the two
+                // hipEventRecord calls of dom_begin / dom_end cost ~10 us of a 160 us step
+                hipExtLaunchKernelGGL(nn_grid_coop_kernel<false>, dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->sorted, c->cell_start, d_q,
+                                      (uint32_t)Q, (uint32_t)c->index_base, perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                dom_done(c);
+            } else
                 nn_grid_coop_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
                                                                    perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
             if (so) {
@@ -811,7 +839,7 @@ int count_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_
         const uint32_t *perm = nullptr;
         static const bool coop = [] { const char *e = std::getenv("PCT_GRID_COOP"); return e ? std::atoi(e) != 0 : true; }();
         PCTCHK(bin_queries(c, d_q, Q, s, &perm, !coop, false));
-        dom_begin(c, s);
+        dom_begin(c, s, coop && !c->count_work);
         if (coop) {   // 8 lanes per query (default)
             const int blocks = ceil_div(Q, 256 / kCoop);
             const float4 *qs = perm ? c->d_qsorted : nullptr;
@@ -1933,9 +1961,9 @@ int pct_plan_destroy(pct_plan *p)
 int pct_last_kernel_ms(pct_cloud *c, float *ms)
 {
     if (!c || !ms) return fail(PCT_ERR_INVALID, "bad arguments");
-    if (!c->dom_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
-    HIPCHK(hipEventSynchronize(c->ev3));
-    HIPCHK(hipEventElapsedTime(ms, c->ev2, c->ev3));
+    if (!c->last3) return fail(PCT_ERR_INVALID, "no timed batch yet");
+    HIPCHK(hipEventSynchronize(c->last3));
+    HIPCHK(hipEventElapsedTime(ms, c->last2, c->last3));
     return PCT_OK;
 }
 
@@ -1964,6 +1992,21 @@ int pct_set_timing(pct_cloud *c, int level)
 {
     if (!c || level < 0 || level > 2) return fail(PCT_ERR_INVALID, "timing level must be 0, 1 or 2");
     c->timing_level = level;
+    return PCT_OK;
+}
+
+int pct_set_timing_stride(pct_cloud *c, int stride)
+{
+    if (!c || stride < 1) return fail(PCT_ERR_INVALID, "timing stride must be >= 1");
+    c->dom_stride = stride;
+    c->dom_launch = 0;
+    return PCT_OK;
+}
+
+int pct_kernel_ms_samples(pct_cloud *c, uint64_t *count)
+{
+    if (!c || !count) return fail(PCT_ERR_INVALID, "bad arguments");
+    *count = c->dom_seq;
     return PCT_OK;
 }
 

@@ -117,6 +117,8 @@ def lib():
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
         L.pct_set_timing.argtypes = [vp, C.c_int]
+        L.pct_set_timing_stride.argtypes = [vp, C.c_int]
+        L.pct_kernel_ms_samples.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.pct_merge_mask_dev.argtypes = [vp, vp, vp, vp, i64, vp]
         L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_set_work_counters.argtypes = [vp, i32]
@@ -358,6 +360,15 @@ class Cloud:
     def set_timing(self, level: int):
         """0 = no events, 1 = dominant kernel only (default), 2 = + whole batch (needed by last_batch_ms)"""
         _chk(lib().pct_set_timing(self._h, int(level)))
+
+    def set_timing_stride(self, stride: int):
+        """the index path times only every stride-th launch from now on (pct_set_timing_stride)"""
+        _chk(lib().pct_set_timing_stride(self._h, int(stride)))
+
+    def kernel_ms_samples(self) -> int:
+        n = C.c_uint64()
+        _chk(lib().pct_kernel_ms_samples(self._h, C.byref(n)))
+        return int(n.value)
 
     def kernel_ms_history(self, n: int = 64):
         """dominant-kernel durations (ms) of the last <= n batches, oldest first (HIP events on the launch stream)"""

@@ -10,6 +10,8 @@ c = E.Cloud(len(pts)); c.set_input(pts); c.build_grid()
 Q = 1 << 20
 q = torch.from_numpy(synth.uniform_points(5, Q, 0, 100)).cuda()
 c.reserve_queries(Q)
+if os.environ.get("PCT_AB_TIMING"):
+    c.set_timing(int(os.environ["PCT_AB_TIMING"]))
 idx = torch.empty(Q, dtype=torch.int32, device="cuda"); d2 = torch.empty(Q, dtype=torch.float64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
 res = []
@@ -18,4 +20,5 @@ for rep in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): c.nn_device(q.data_ptr(), Q, idx.data_ptr(), d2.data_ptr(), s, E.ALGO_GRID)
     torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 30 * 1e3)
-print("ms/step median %.4f min %.4f" % (float(np.median(res)), min(res)))
+km = c.kernel_ms_history(30) if int(os.environ.get("PCT_AB_TIMING", "1")) >= 1 else [float("nan")]
+print("ms/step median %.4f min %.4f  kernel_ms (events) mean %.4f" % (float(np.median(res)), min(res), float(np.mean(km))))

@@ -678,3 +678,35 @@ def test_stream_variants_of_inflate_and_bezier(E, kind):
         same = np.all(d_pos.cpu().numpy()[:m].astype(np.float32) == want["pos"].astype(np.float32), axis=1)
         assert np.array_equal(d_rad.cpu().numpy()[:m][same], want["radius"][same]) and np.array_equal(d_d2.cpu().numpy()[:m][same], want["d2"][same])
     c.close()
+
+
+def test_kernel_timing_stride_and_sample_counter(E, oracle):
+    """pct_set_timing_stride / pct_kernel_ms_samples (what bench.py's roofline leg reads): with stride 4 the index path records the
+    dominant kernel of launches 0, 4, 8 ...; the sampled durations are plausible (positive, below the batch's wall time) and the
+    answers do not depend on whether a launch was timed"""
+    import time
+    import torch
+    pts = synth.uniform_points(3, 400_000, 0, 50)
+    qh = synth.uniform_points(5, 60_000, 0, 50)
+    c = make_cloud(E, pts, grid=True)
+    c.reserve_queries(len(qh))
+    q = torch.from_numpy(qh).cuda()
+    idx = torch.empty(len(qh), dtype=torch.int32, device="cuda")
+    d2 = torch.empty(len(qh), dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    wi, wd = oracle.brute_nearest(pts, qh)
+    for stride, launches, want in ((1, 5, 5), (4, 9, 3), (4, 4, 1)):
+        c.set_timing_stride(stride)
+        n0 = c.kernel_ms_samples()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            c.nn_device(q.data_ptr(), len(qh), idx.data_ptr(), d2.data_ptr(), s, E.ALGO_GRID)
+        torch.cuda.synchronize()
+        wall_ms = 1e3 * (time.perf_counter() - t0)
+        assert c.kernel_ms_samples() - n0 == want
+        ms = c.kernel_ms_history(want)
+        assert len(ms) == want and all(0.0 < m < wall_ms for m in ms), (ms, wall_ms)
+        assert 0.0 < c.last_kernel_ms() < wall_ms
+        assert np.array_equal(idx.cpu().numpy().view(np.uint32), wi) and np.array_equal(d2.cpu().numpy(), wd)
+    c.close()

@@ -105,7 +105,7 @@ def test_bench_two_ranks_on_one_card():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--points-total", "4000000",
-                        "--queries", "65536"], env=env, capture_output=True, text=True, timeout=900)
+                        "--queries", "65536", "--preheat-steps", "10"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
