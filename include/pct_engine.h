@@ -300,6 +300,9 @@ int pct_set_work_counters(pct_cloud *c, int enabled);
 int pct_debug_set_filter_mode(int mode);
 /* diagnostics: the fp32 upper bounds the streaming filter used for the last batch */
 int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q);
+/* test hook: copies of the cell index as built -- cell_start[ncells + 1] and the cell-ordered records (4 floats per point:
+ * x, y, z, bit-cast original index); either pointer may be NULL */
+int pct_debug_read_grid(pct_cloud *c, uint32_t *cell_start, float *records);
 
 #ifdef __cplusplus
 }

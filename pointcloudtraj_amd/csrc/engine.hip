@@ -23,6 +23,7 @@
 #include "../../include/pct_engine.h"
 #include "engine_internal.hpp"
 #include "kernels.hpp"
+#include "gridbuild.hpp"
 #include "ring.hpp"
 #include "brute2.hpp"
 
@@ -101,6 +102,10 @@ struct pct_cloud {
     int64_t cap = 0, cap4 = 0, count = 0, ring_next = 0;
     int64_t index_base = 0;
     float *x = nullptr, *y = nullptr, *z = nullptr;
+    float4 *gb_tmp = nullptr;                   // index build scratch (gridbuild.hpp): slab-ordered records, kept between builds
+    size_t gb_tmp_cap = 0;
+    uint32_t *gb_small = nullptr;               // per-block slab table + slab totals / cursors / starts
+    size_t gb_small_cap = 0;
     // "small" clouds keep their coordinates in host-mapped memory (kernels read them over the bus; the host
     // appends with plain stores and no launch) -- the RRT* node sets of the kd_* drop-in
     bool host_mapped = false;
@@ -288,6 +293,67 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
         PCTCHK(dev_alloc(sorted, (size_t)n));
         *sorted_cap = (size_t)n;
     }
+    // ---- two-level counting sort on LDS histograms (gridbuild.hpp): no device-scope atomic per point ----
+    static const bool lds_build = [] { const char *e = std::getenv("PCT_LDS_GRID_BUILD"); return e ? std::atoi(e) != 0 : true; }();
+    // slabs of 2^s1 consecutive cells, sized for ~2-6 k points each (level 2 then holds a whole slab in LDS), at most kGbMaxSlabs;
+    // more, smaller slabs make level 1 slower (more open write streams, more LDS per block) faster than they help level 2
+    const uint64_t want_slabs = std::min<uint64_t>((uint64_t)kGbMaxSlabs, std::max<uint64_t>(64, (uint64_t)n / 2048));
+    int s1 = 0;
+    while (((ncells + (1ull << s1) - 1) >> s1) > want_slabs) s1++;
+    if (lds_build && n >= 4096 && (1u << s1) <= (uint32_t)kGbMaxSlabCells && (uint64_t)n < 0xFFFFFFF0ull) {
+        GbDesc D{};
+        D.s1 = s1;
+        D.nslabs = (uint32_t)((ncells + (1ull << s1) - 1) >> s1);
+        const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(kGbMaxBlocks, (n + 16383) / 16384));
+        D.chunk = (uint32_t)((((n + nblk - 1) / nblk) + 3) & ~3ll);
+        const int blocks = (int)((n + D.chunk - 1) / D.chunk);
+        // level-2 block size by the mean slab: a block holds up to 8 records per thread in LDS (larger slabs stream through twice)
+        static const int stage_on = [] { const char *e = std::getenv("PCT_GB_STAGE"); return e ? std::atoi(e) : 1; }();
+        const double mean_slab = (double)n / D.nslabs;
+        const int cthreads = mean_slab <= 1400 ? 256 : mean_slab <= 3000 ? 512 : 1024;
+        const size_t lds1 = sizeof(uint32_t) * ((size_t)D.nslabs + 1);
+        const size_t lds_cnt = sizeof(uint32_t) * ((((size_t)1 << s1) + 1 + 3) & ~(size_t)3);
+        const uint32_t stage_cap = stage_on ? (uint32_t)std::min<size_t>((size_t)kGbStagePerThread * cthreads, (150 * 1024 - lds_cnt) / sizeof(float4)) : 0u;
+        const size_t lds2 = lds_cnt + sizeof(float4) * stage_cap;
+        static bool attr = false;
+        if (!attr) {      // more than the default 64 KiB of LDS per block (gfx950: 160 KiB per CU)
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gb_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gb_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gb_cells_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gb_cells_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(gb_cells_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr = true;
+        }
+        // scratch kept with the cloud (a rebuild per sensor frame must not pay hipMalloc / hipFree): records + table + slab counters
+        if ((size_t)n > c->gb_tmp_cap) {
+            dev_free(c->gb_tmp);
+            c->gb_tmp_cap = 0;
+            PCTCHK(dev_alloc(&c->gb_tmp, (size_t)n));
+            c->gb_tmp_cap = (size_t)n;
+        }
+        const size_t small_need = (size_t)blocks * D.nslabs + 3 * (size_t)D.nslabs + 8;
+        if (small_need > c->gb_small_cap) {
+            dev_free(c->gb_small);
+            c->gb_small_cap = 0;
+            PCTCHK(dev_alloc(&c->gb_small, small_need));
+            c->gb_small_cap = small_need;
+        }
+        uint32_t *table = c->gb_small, *slab_total = table + (size_t)blocks * D.nslabs, *slab_cursor = slab_total + D.nslabs,
+                 *slab_start = slab_cursor + D.nslabs;
+        hipError_t e = hipMemsetAsync(slab_total, 0, sizeof(uint32_t) * 2 * D.nslabs, s);
+        if (e == hipSuccess) {
+            gb_hist_kernel<<<blocks, kGbThreads, lds1, s>>>(G, D, c->x, c->y, c->z, (uint32_t)n, table, slab_total);
+            gb_scatter_kernel<<<blocks, kGbThreads, lds1, s>>>(G, D, c->x, c->y, c->z, (uint32_t)n, table, slab_total, slab_cursor, slab_start, c->gb_tmp);
+            if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+            else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+            else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
+        return PCT_OK;
+    }
+    // ---- small clouds / very fine user-given cells: one device atomic per point and pass ----
     uint32_t *d_cnt = nullptr, *d_pcell = nullptr, *d_tiles = nullptr;
     const uint32_t ntiles = (uint32_t)((ncells + kScanTile - 1) / kScanTile);
     int st = dev_alloc(&d_cnt, ncells);
@@ -563,13 +629,12 @@ int cloud_bbox_cached(pct_cloud *c)
     hipStream_t s = g_stream;
     const int64_t n = c->count;
     const int bblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
-    float *d_part = nullptr;
-    PCTCHK(dev_alloc(&d_part, (size_t)bblocks * 6));
+    PCTCHK(ensure_stage(c, sizeof(float) * (size_t)bblocks * 6));     // the upload staging buffer is idle here: no allocation per build
+    float *d_part = reinterpret_cast<float *>(c->d_stage);
     bbox_partial_kernel<<<bblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_part);
     std::vector<float> part((size_t)bblocks * 6);
     hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    dev_free(d_part);
     if (e != hipSuccess) return fail(PCT_ERR_HIP, "bbox reduction failed: %s", hipGetErrorString(e));
     for (int k = 0; k < 3; k++) { c->bbox_lo[k] = INFINITY; c->bbox_hi[k] = -INFINITY; }
     for (int b = 0; b < bblocks; b++)
@@ -1047,7 +1112,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_aux) (void)hipHostFree(c->h_aux);
     if (c->h_eout) (void)hipHostFree(c->h_eout);
     if (c->h_bpos) (void)hipHostFree(c->h_bpos);
-    dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage);
+    dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage); dev_free(c->gb_tmp); dev_free(c->gb_small);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
@@ -1224,13 +1289,12 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
 
     // 1. bounding box
     const int bblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
-    float *d_part = nullptr;
-    PCTCHK(dev_alloc(&d_part, (size_t)bblocks * 6));
+    PCTCHK(ensure_stage(c, sizeof(float) * (size_t)bblocks * 6));     // the upload staging buffer is idle here: no allocation per build
+    float *d_part = reinterpret_cast<float *>(c->d_stage);
     bbox_partial_kernel<<<bblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_part);
     std::vector<float> part((size_t)bblocks * 6);
     hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    dev_free(d_part);
     if (e != hipSuccess) return fail(PCT_ERR_HIP, "bbox reduction failed: %s", hipGetErrorString(e));
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (int b = 0; b < bblocks; b++)
@@ -1277,20 +1341,23 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     // 4. sparse occupancy (points on surfaces): add coarser levels so free-space queries do not walk empty fine shells
     c->C.n = 0;
     {
-        uint32_t *d_empty = nullptr, n_empty = 0;
-        PCTCHK(dev_alloc(&d_empty, 1));
-        hipError_t e2 = hipMemsetAsync(d_empty, 0, sizeof(uint32_t), s);
-        count_empty_cells_kernel<<<(int)std::min<uint64_t>(1024, (ncells + 255) / 256), 256, 0, s>>>(c->cell_start, (uint32_t)ncells, d_empty);
-        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&n_empty, d_empty, sizeof n_empty, hipMemcpyDeviceToHost, s);
-        if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
-        dev_free(d_empty);
-        if (e2 != hipSuccess) return fail(PCT_ERR_HIP, "occupancy count failed: %s", hipGetErrorString(e2));
         // OFF by default (threshold > 1): measured on the seed-6 pillar map the coarse cubes cut the cell rows visited per
         // free-space query from 307 to 17 but raise the points examined from 869 to 18 000 (a cube four times wider holds
         // sixteen times more SURFACE points), 3.5x slower overall -- walking fine shells is the better trade for surface
         // clouds.  Kept selectable (PCT_PYRAMID_EMPTY_FRAC=0.5) and covered by tests for volumetric sparse clouds.
         double sparse_at = 2.0;
         if (const char *ev = std::getenv("PCT_PYRAMID_EMPTY_FRAC")) sparse_at = std::atof(ev);
+        uint32_t n_empty = 0;
+        if (sparse_at < 1.0) {                 // the occupancy count (a launch + a host round trip) only when the levels can be asked for
+            uint32_t *d_empty = nullptr;
+            PCTCHK(dev_alloc(&d_empty, 1));
+            hipError_t e2 = hipMemsetAsync(d_empty, 0, sizeof(uint32_t), s);
+            count_empty_cells_kernel<<<(int)std::min<uint64_t>(1024, (ncells + 255) / 256), 256, 0, s>>>(c->cell_start, (uint32_t)ncells, d_empty);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(&n_empty, d_empty, sizeof n_empty, hipMemcpyDeviceToHost, s);
+            if (e2 == hipSuccess) e2 = hipStreamSynchronize(s);
+            dev_free(d_empty);
+            if (e2 != hipSuccess) return fail(PCT_ERR_HIP, "occupancy count failed: %s", hipGetErrorString(e2));
+        }
         if ((double)n_empty > sparse_at * (double)ncells && ncells > 512) {
             GridDesc L = G;
             for (int l = 0; l < kMaxCoarse && std::max({ L.gx, L.gy, L.gz }) > 3; l++) {
@@ -2030,6 +2097,16 @@ int pct_last_batch_ms(pct_cloud *c, float *ms)
     if (!c->ev_valid) return fail(PCT_ERR_INVALID, "no timed batch yet");
     HIPCHK(hipEventSynchronize(c->ev1));
     HIPCHK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return PCT_OK;
+}
+
+// test hook: the cell index as built (cell_start: ncells + 1 entries, records: 4 floats per point = x, y, z, bit-cast index)
+int pct_debug_read_grid(pct_cloud *c, uint32_t *cell_start, float *records)
+{
+    if (!c || !c->has_grid) return fail(PCT_ERR_INVALID, "no cell index");
+    HIPCHK(hipStreamSynchronize(g_stream));
+    if (cell_start) HIPCHK(hipMemcpy(cell_start, c->cell_start, sizeof(uint32_t) * ((size_t)c->G.ncells + 1), hipMemcpyDeviceToHost));
+    if (records) HIPCHK(hipMemcpy(records, c->sorted, sizeof(float4) * (size_t)c->count, hipMemcpyDeviceToHost));
     return PCT_OK;
 }
 

@@ -1,0 +1,189 @@
+// gridbuild.hpp -- building the uniform-cell index as a two-level counting sort on LDS histograms.
+//
+// What it replaces: cell_histogram_kernel + cell_scatter_kernel (kernels.hpp) issue one device-scope atomic per point and pass;
+// scattered device atomics execute at the memory side at ~20 G/s chip-wide, so the 100 M-point cloud of config C4 spent
+// 3.7 + 5.7 ms in those two kernels (profiles/r02_c4_kernel_stats.csv) where its 4 GB of traffic need under 1 ms.
+//
+// Level 1: the cell range is cut into <= 16384 slabs of 2^s1 consecutive cells (cell order: x fastest, then y, then z).  Every
+//          block histograms a contiguous chunk of the cloud over the slabs in LDS (gb_hist_kernel: one global atomic per block and
+//          non-empty slab), then reserves its share of every slab with one more atomic and moves its points there as
+//          {x, y, z, index} records (gb_scatter_kernel).
+// Level 2: one block per slab histograms the slab's records over its 2^s1 cells in LDS, scans, writes that piece of cell_start
+//          and drops every record into its cell (gb_cells_kernel) -- all writes of a block land in the slab's own window.
+// No device-scope atomic per point anywhere; the order of the records inside a cell is arbitrary, which every consumer tolerates
+// (winners are picked by (d2, index), counts are counts).  The reference rebuilds its kd-tree from the cloud on every sensor frame
+// (corridor_finder.cpp:93-99); this is that step for the cell index.
+#pragma once
+
+namespace pct {
+
+constexpr int kGbThreads = 1024;
+constexpr int kGbMaxSlabs = 16384;       // LDS histogram of level 1 (dynamic LDS: 4 bytes per slab, 64 KiB at most: two blocks per CU)
+constexpr int kGbMaxSlabCells = 8192;    // LDS histogram of level 2 (32 KiB)
+constexpr int kGbMaxBlocks = 512;
+
+struct GbDesc {
+    int s1;                // slab = cell >> s1
+    uint32_t nslabs;       // <= kGbMaxSlabs
+    uint32_t chunk;        // points per block of level 1 (multiple of 4)
+};
+
+__device__ __forceinline__ uint32_t gb_cell(const GridDesc &G, float px, float py, float pz)
+{
+    return cell_lin(G, cell_coord(px, G.ox, G.inv_h, G.gx), cell_coord(py, G.oy, G.inv_h, G.gy), cell_coord(pz, G.oz, G.inv_h, G.gz));
+}
+
+// level 1, pass A: table[block][slab] = points of the block's chunk in the slab; slab_total[slab] += the same
+__global__ __launch_bounds__(kGbThreads) void gb_hist_kernel(GridDesc G, GbDesc D, const float *__restrict__ x, const float *__restrict__ y,
+                                                             const float *__restrict__ z, uint32_t n, uint32_t *__restrict__ table,
+                                                             uint32_t *__restrict__ slab_total)
+{
+    extern __shared__ uint32_t h[];                                  // nslabs counters
+    for (uint32_t i = threadIdx.x; i < D.nslabs; i += kGbThreads) h[i] = 0;
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * D.chunk, b1 = min(n, b0 + D.chunk);
+    const uint32_t full = b0 + ((b1 - b0) & ~3u);                    // whole groups of 4 points: one 16-byte load per array
+    for (uint32_t i = b0 + 4 * threadIdx.x; i < full; i += 4 * kGbThreads) {
+        const float4 X = *reinterpret_cast<const float4 *>(x + i), Y = *reinterpret_cast<const float4 *>(y + i),
+                     Z = *reinterpret_cast<const float4 *>(z + i);
+        atomicAdd(&h[gb_cell(G, X.x, Y.x, Z.x) >> D.s1], 1u);
+        atomicAdd(&h[gb_cell(G, X.y, Y.y, Z.y) >> D.s1], 1u);
+        atomicAdd(&h[gb_cell(G, X.z, Y.z, Z.z) >> D.s1], 1u);
+        atomicAdd(&h[gb_cell(G, X.w, Y.w, Z.w) >> D.s1], 1u);
+    }
+    for (uint32_t i = full + threadIdx.x; i < b1; i += kGbThreads) atomicAdd(&h[gb_cell(G, x[i], y[i], z[i]) >> D.s1], 1u);
+    __syncthreads();
+    uint32_t *row = table + (size_t)blockIdx.x * D.nslabs;
+    for (uint32_t i = threadIdx.x; i < D.nslabs; i += kGbThreads) {
+        const uint32_t v = h[i];
+        row[i] = v;
+        if (v) atomicAdd(&slab_total[i], v);
+    }
+}
+
+// exclusive scan of a[0..n) in LDS by the whole block, n <= blockDim.x * 16 handled in rounds with a carry; a[n] = total
+template <int THREADS>
+__device__ __forceinline__ void gb_block_scan(uint32_t *a, uint32_t n, uint32_t *s_wave, uint32_t *s_carry)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) *s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += THREADS) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? a[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t wave_off = *s_carry;
+        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+        if (i < n) a[i] = wave_off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == THREADS - 1) *s_carry = wave_off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a[n] = *s_carry;
+    __syncthreads();
+}
+
+// level 1, pass B: every block scans the slab totals (4096 values: cheaper than a launch of its own), reserves its share of every
+// slab it has points for, and moves its chunk.  Block 0 also publishes slab_start for level 2.
+__global__ __launch_bounds__(kGbThreads) void gb_scatter_kernel(GridDesc G, GbDesc D, const float *__restrict__ x, const float *__restrict__ y,
+                                                                const float *__restrict__ z, uint32_t n, const uint32_t *__restrict__ table,
+                                                                const uint32_t *__restrict__ slab_total, uint32_t *__restrict__ slab_cursor,
+                                                                uint32_t *__restrict__ slab_start, float4 *__restrict__ tmp)
+{
+    extern __shared__ uint32_t base[];                               // nslabs + 1 entries
+    __shared__ uint32_t s_wave[kGbThreads / 64], s_carry;
+    for (uint32_t i = threadIdx.x; i < D.nslabs; i += kGbThreads) base[i] = slab_total[i];
+    __syncthreads();
+    gb_block_scan<kGbThreads>(base, D.nslabs, s_wave, &s_carry);
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i <= D.nslabs; i += kGbThreads) slab_start[i] = base[i];
+    const uint32_t *row = table + (size_t)blockIdx.x * D.nslabs;
+    for (uint32_t i = threadIdx.x; i < D.nslabs; i += kGbThreads) {
+        const uint32_t v = row[i];
+        if (v) base[i] += atomicAdd(&slab_cursor[i], v);             // this block's first slot in slab i
+    }
+    __syncthreads();
+    const uint32_t b0 = blockIdx.x * D.chunk, b1 = min(n, b0 + D.chunk);
+    const uint32_t full = b0 + ((b1 - b0) & ~3u);
+    for (uint32_t i = b0 + 4 * threadIdx.x; i < full; i += 4 * kGbThreads) {
+        const float4 X = *reinterpret_cast<const float4 *>(x + i), Y = *reinterpret_cast<const float4 *>(y + i),
+                     Z = *reinterpret_cast<const float4 *>(z + i);
+        tmp[atomicAdd(&base[gb_cell(G, X.x, Y.x, Z.x) >> D.s1], 1u)] = make_float4(X.x, Y.x, Z.x, __uint_as_float(i));
+        tmp[atomicAdd(&base[gb_cell(G, X.y, Y.y, Z.y) >> D.s1], 1u)] = make_float4(X.y, Y.y, Z.y, __uint_as_float(i + 1));
+        tmp[atomicAdd(&base[gb_cell(G, X.z, Y.z, Z.z) >> D.s1], 1u)] = make_float4(X.z, Y.z, Z.z, __uint_as_float(i + 2));
+        tmp[atomicAdd(&base[gb_cell(G, X.w, Y.w, Z.w) >> D.s1], 1u)] = make_float4(X.w, Y.w, Z.w, __uint_as_float(i + 3));
+    }
+    for (uint32_t i = full + threadIdx.x; i < b1; i += kGbThreads) {
+        const float px = x[i], py = y[i], pz = z[i];
+        tmp[atomicAdd(&base[gb_cell(G, px, py, pz) >> D.s1], 1u)] = make_float4(px, py, pz, __uint_as_float(i));
+    }
+}
+
+// level 2: block b owns slab b = cells [b << s1, min(ncells, (b + 1) << s1)) = records tmp[slab_start[b], slab_start[b + 1]).
+// A slab of at most stage_cap records (the normal case: the host sizes the slabs for ~1-6 k points) is read ONCE into registers,
+// ranked through the LDS cell counters, placed in LDS at its sorted position and written out as one contiguous run -- whole
+// lines, no second read.  A larger slab (clustered clouds) streams through twice and scatters inside its own window.
+// Dynamic LDS: (2^s1 + 1) counters, padded to 16 bytes, then stage_cap float4 records.
+constexpr int kGbStagePerThread = 8;                                 // stage_cap <= 8 records per thread
+template <int kGbCellThreads>
+__global__ __launch_bounds__(kGbCellThreads) void gb_cells_kernel(GridDesc G, GbDesc D, const uint32_t *__restrict__ slab_start,
+                                                                  const float4 *__restrict__ tmp, uint32_t n, uint32_t stage_cap,
+                                                                  uint32_t *__restrict__ cell_start, float4 *__restrict__ sorted)
+{
+    extern __shared__ uint32_t cnt[];
+    __shared__ uint32_t s_wave[kGbCellThreads / 64], s_carry;
+    float4 *stage = reinterpret_cast<float4 *>(cnt + ((((1u << D.s1) + 1) + 3) & ~3u));
+    const uint32_t b = blockIdx.x;
+    const uint32_t c0 = b << D.s1, c1 = min(G.ncells, c0 + (1u << D.s1)), m = c1 - c0;
+    const uint32_t p0 = slab_start[b], p1 = slab_start[b + 1], np = p1 - p0;
+    for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) cnt[i] = 0;
+    __syncthreads();
+    if (np <= stage_cap) {
+        float4 R[kGbStagePerThread];
+        uint32_t cell[kGbStagePerThread];
+#pragma unroll
+        for (int k = 0; k < kGbStagePerThread; k++) {
+            const uint32_t i = threadIdx.x + k * kGbCellThreads;
+            if (i < np) {
+                R[k] = tmp[p0 + i];
+                cell[k] = gb_cell(G, R[k].x, R[k].y, R[k].z) - c0;
+                atomicAdd(&cnt[cell[k]], 1u);
+            }
+        }
+        __syncthreads();
+        gb_block_scan<kGbCellThreads>(cnt, m, s_wave, &s_carry);
+        for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) cell_start[c0 + i] = p0 + cnt[i];
+        if (c1 == G.ncells && threadIdx.x == 0) cell_start[G.ncells] = n;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kGbStagePerThread; k++) {
+            const uint32_t i = threadIdx.x + k * kGbCellThreads;
+            if (i < np) stage[atomicAdd(&cnt[cell[k]], 1u)] = R[k];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < np; i += kGbCellThreads) sorted[p0 + i] = stage[i];
+        return;
+    }
+    for (uint32_t i = p0 + threadIdx.x; i < p1; i += kGbCellThreads) {
+        const float4 P = tmp[i];
+        atomicAdd(&cnt[gb_cell(G, P.x, P.y, P.z) - c0], 1u);
+    }
+    __syncthreads();
+    gb_block_scan<kGbCellThreads>(cnt, m, s_wave, &s_carry);
+    for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) cell_start[c0 + i] = p0 + cnt[i];
+    if (c1 == G.ncells && threadIdx.x == 0) cell_start[G.ncells] = n;
+    __syncthreads();
+    for (uint32_t i = p0 + threadIdx.x; i < p1; i += kGbCellThreads) {
+        const float4 P = tmp[i];
+        sorted[p0 + atomicAdd(&cnt[gb_cell(G, P.x, P.y, P.z) - c0], 1u)] = P;
+    }
+}
+
+}  // namespace pct

@@ -116,6 +116,7 @@ def lib():
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        L.pct_debug_read_grid.argtypes = [vp, vp, vp]
         L.pct_set_timing.argtypes = [vp, C.c_int]
         L.pct_set_timing_stride.argtypes = [vp, C.c_int]
         L.pct_kernel_ms_samples.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -360,6 +361,13 @@ class Cloud:
     def set_timing(self, level: int):
         """0 = no events, 1 = dominant kernel only (default), 2 = + whole batch (needed by last_batch_ms)"""
         _chk(lib().pct_set_timing(self._h, int(level)))
+
+    def debug_read_grid(self):
+        """(cell_start uint32 [ncells + 1], records float32 [n, 4]) as built -- test hook"""
+        cs = np.empty(self.grid_info()["ncells"] + 1, np.uint32)
+        rec = np.empty((len(self), 4), np.float32)
+        _chk(lib().pct_debug_read_grid(self._h, cs.ctypes.data, rec.ctypes.data))
+        return cs, rec
 
     def set_timing_stride(self, stride: int):
         """the index path times only every stride-th launch from now on (pct_set_timing_stride)"""

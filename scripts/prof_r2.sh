@@ -1,6 +1,6 @@
 # rocprofv3 passes of round 2 (program directly after `--`); summaries are condensed by scripts/collect_profiles.py into
 # gpurun_out/prof_<tag>/summary_* and copied to profiles/ by hand.   usage: bash scripts/prof_r2.sh <what> [tag]
-#   what = bench | bench_sorted | c4 | c5 | brute
+#   what = bench | bench_sorted | c4 | c5 | brute | build
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 WHAT=${1:-bench}
@@ -13,6 +13,7 @@ case $WHAT in
   c4)           CMD="scripts/probe_c4.py" ;;
   c5)           CMD="scripts/probe_c5.py 100" ;;
   brute)        CMD="scripts/probe_brute.py" ;;
+  build)        CMD="scripts/probe_build.py 10000000 100000000" ;;
 esac
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $CMD > $OUT/run_trace.log 2>&1
 echo trace_rc=$?

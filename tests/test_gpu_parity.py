@@ -710,3 +710,51 @@ def test_kernel_timing_stride_and_sample_counter(E, oracle):
         assert 0.0 < c.last_kernel_ms() < wall_ms
         assert np.array_equal(idx.cpu().numpy().view(np.uint32), wi) and np.array_equal(d2.cpu().numpy(), wd)
     c.close()
+
+
+def _check_cell_index(c, pts):
+    """structure of the built index: cell_start is a prefix of the point counts, every record sits in the cell its coordinates
+    map to (the fp32 assignment queries use), and the records are a permutation of the cloud"""
+    info = c.grid_info()
+    cs, rec = c.debug_read_grid()
+    n = len(pts)
+    assert cs[0] == 0 and cs[-1] == n and np.all(np.diff(cs.astype(np.int64)) >= 0)
+    ids = rec[:, 3].copy().view(np.uint32)
+    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    assert np.array_equal(rec[:, :3], pts[ids])
+    gx, gy, gz = info["dims"]
+    o = np.float32(info["origin"])
+    inv_h = np.float32(1.0) / np.float32(info["cell_size"])
+    cc = [np.clip(np.floor((rec[:, k] - o[k]) * inv_h), 0, g - 1).astype(np.int64) for k, g in enumerate((gx, gy, gz))]
+    cell = (cc[2] * gy + cc[1]) * gx + cc[0]
+    pos = np.arange(n)
+    assert np.all(cs[cell] <= pos) and np.all(pos < cs[cell + 1])
+
+
+@pytest.mark.parametrize("shape", ["uniform_1m", "ragged_n", "clustered", "identical", "two_cells", "fine_cells", "small"])
+def test_cell_index_structure(E, oracle, shape):
+    """the two-level LDS counting sort (gridbuild.hpp) and the per-point-atomic build it falls back to for small clouds / very fine
+    cells: same structural contract, and NN answers through the index equal the oracle's"""
+    cell = 0.0
+    if shape == "uniform_1m":
+        pts = synth.uniform_points(3, 1_000_000, 0, 100)
+    elif shape == "ragged_n":
+        pts = synth.uniform_points(3, 70_001, -5, 5)                    # not a multiple of 4: scalar tails of the chunk loops
+    elif shape == "clustered":
+        pts = synth.clustered_points(8, 300_000, 0, 30)                 # most slabs empty, a few hold most points
+    elif shape == "identical":
+        pts = np.tile(np.float32([[1.5, -2.0, 0.25]]), (50_000, 1))    # one cell holds everything
+    elif shape == "two_cells":
+        pts = np.concatenate([np.tile(np.float32([[0, 0, 0]]), (30_000, 1)), np.tile(np.float32([[10, 10, 10]]), (30_001, 1))])
+    elif shape == "fine_cells":
+        pts = synth.uniform_points(3, 200_000, 0, 100)
+        cell = 0.25                                                     # 6.4e7 cells: beyond the LDS build's 4096 x 8192, atomic path
+    else:
+        pts = synth.uniform_points(3, 3000, 0, 10)                      # below the LDS build's threshold
+    c = make_cloud(E, pts, grid=True, cell=cell)
+    _check_cell_index(c, pts)
+    qh = np.concatenate([synth.uniform_points(5, 4000, -6, 106), pts[:: max(1, len(pts) // 500)][:500]])
+    idx, d2 = c.nn(qh, E.ALGO_GRID)
+    wi, wd = oracle.brute_nearest(pts, qh)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+    c.close()
