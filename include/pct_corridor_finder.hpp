@@ -1,27 +1,30 @@
 // pct_corridor_finder.hpp -- "safe-region RRT*" flight-corridor finder on the MI355X engine.
 //
-// Host-side mirror of the reference's safeRegionRrtStar (Planner/include/pointcloudTraj/corridor_finder.h:17-150,
-// Planner/src/corridor_finder.cpp) with the same public surface (setParam, reset, setInput, setPt, setStartPt,
-// resetRoot, SafeRegionExpansion / Refine / Evaluate, checkTrajPtCol, getPath, getTree, getPathExistStatus,
-// getGlobalNaviStatus) and the same bookkeeping, but:
-//   * the obstacle cloud lives in HBM behind pct::ObstacleMap -- every radiusSearch / checkRadius is the HIP
-//     inflation path (pct_inflate_batch); the independent re-checks of SafeRegionEvaluate run as ONE batch per pass;
-//   * the RRT* node set is the drop-in kd_* API (libkdtree.so), i.e. also answered on the GPU;
-//   * the wall-clock boxes (ros::Time checks at corridor_finder.cpp:721-722, 774-775, 900-901, 950-951) are
-//     replaced by iteration counts so that a run is deterministic and comparable;
-//   * Eigen is replaced by a 3-double struct; std::default_random_engine / uniform_real_distribution by an own
-//     minstd_rand0 + generate_canonical<double,53> (what libstdc++ does), so results do not depend on the host library.
-//   * setSpeculation(K): the sampling loop may run K samples ahead on the GPU (three batched launches per K samples)
-//     and replay them in order on the host, falling back to the one-by-one path whenever an earlier sample of the batch
-//     changed what a later one would have seen -- the accepted nodes, and so the corridor, are identical to K = 1.
-// Numeric types follow data_type.h:12-51 exactly (Node::radius, g, f, rel_dis are float; coordinates double).
+// Same public surface and the same decisions, sample for sample, as the reference's safeRegionRrtStar
+// (Planner/include/pointcloudTraj/corridor_finder.h:17-150, Planner/src/corridor_finder.cpp): setParam, reset, setInput,
+// setPt, setStartPt, resetRoot, SafeRegionExpansion / Refine / Evaluate, checkTrajPtCol, getPath, getTree,
+// getPathExistStatus, getGlobalNaviStatus.  The machinery underneath is this library's own:
+//   * the search tree is an ARENA of spheres addressed by 32-bit ids (detail::SphereArena: centre / radius / cost arrays,
+//     parent + intrusive sibling links, a free list) instead of heap nodes holding pointer vectors -- O(1) re-parenting,
+//     no per-node scratch fields, nothing to leak or free twice, and the arrays are what a batch hands to the GPU;
+//   * the obstacle cloud lives in HBM behind pct::ObstacleMap: every clearance query (the reference's radiusSearch /
+//     checkRadius, corridor_finder.cpp:113-133) is the HIP inflation path; SafeRegionEvaluate's re-checks and the repair
+//     pass after it run as ONE batch per pass;
+//   * the tree's nearest / range queries go through the kd_* drop-in (libkdtree.so), i.e. they are answered on the GPU too;
+//   * the sampling loop may run K samples ahead (setSpeculation): one fused launch answers nearest node -> steer ->
+//     clearance -> neighbourhood for K samples against a snapshot of the tree, the host replays them in order and falls back
+//     whenever an earlier sample of the batch changed what a later one would have seen -- the accepted spheres, and so the
+//     corridor, are identical to K = 1;
+//   * the wall-clock limits (ros::Time checks at corridor_finder.cpp:721-722, 774-775, 900-901, 950-951) are iteration counts,
+//     so a run is deterministic and comparable; Eigen is a 3-double struct; std::default_random_engine +
+//     uniform_real_distribution are an own minstd_rand0 + the two-draw generate_canonical recipe of libstdc++.
+// Numeric types follow data_type.h:12-51 (radius, g, f are float; coordinates double): that is part of the behaviour.
 #pragma once
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
-#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -42,21 +45,6 @@ struct Vec3 {
     double norm() const { return std::sqrt(x * x + y * y + z * z); }
     Vec3 normalized() const { const double n2 = x * x + y * y + z * z; return n2 > 0 ? *this / std::sqrt(n2) : *this; }
     Vec3 cross(const Vec3 &o) const { return { y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x }; }
-};
-
-// data_type.h:12-51
-struct CorridorNode {
-    Vec3 coord;
-    float radius = 0;
-    bool valid = true, best = false, change = false;
-    int rel_id = -2;
-    float rel_dis = -1.0f;
-    CorridorNode *preNode_ptr = nullptr;
-    std::vector<CorridorNode *> nxtNode_ptr;
-    float g = 0, f = 0;
-    int32_t kd_index = -1;          // node number in the kd tree (since its last rebuild): where the node's steer data lives
-    CorridorNode() = default;
-    CorridorNode(const Vec3 &c, float r, float g_, float f_) : coord(c), radius(r), g(g_), f(f_) {}
 };
 
 // std::minstd_rand0 + the libstdc++ recipe of uniform_real_distribution<double> (two draws per double)
@@ -80,810 +68,842 @@ private:
     uint32_t x_;
 };
 
+// what getTree() hands out per sphere (data_type.h:12-51 by value; parent = position of the parent in the same list, -1 = none)
+struct CorridorNode {
+    Vec3 coord;
+    float radius = 0, g = 0, f = 0;
+    bool valid = true, best = false;
+    int32_t parent = -1;
+};
+
+namespace detail {
+
+// The search tree's storage: spheres addressed by id, structure-of-arrays, children as an intrusive doubly linked sibling list
+// (the order of siblings never influences a decision of the algorithm, so attaching is a push-front).
+class SphereArena {
+public:
+    static constexpr int32_t kNone = -1;
+    std::vector<Vec3> centre;
+    std::vector<float> radius, cost, heur;          // data_type.h: radius, g (cost from the root), f (distance to the goal)
+    std::vector<int32_t> parent, kd_slot;           // kd_slot: node number in the kd tree since its last rebuild
+    std::vector<uint8_t> alive, on_best, condemned;
+
+    int32_t create(const Vec3 &c, float r, float g, float f)
+    {
+        int32_t id;
+        if (!free_.empty()) { id = free_.back(); free_.pop_back(); }
+        else {
+            id = (int32_t)centre.size();
+            centre.emplace_back(); radius.push_back(0); cost.push_back(0); heur.push_back(0);
+            parent.push_back(kNone); kd_slot.push_back(-1); alive.push_back(0); on_best.push_back(0); condemned.push_back(0);
+            head_.push_back(kNone); next_.push_back(kNone); prev_.push_back(kNone);
+        }
+        centre[id] = c; radius[id] = r; cost[id] = g; heur[id] = f;
+        parent[id] = kNone; kd_slot[id] = -1; alive[id] = 1; on_best[id] = 0; condemned[id] = 0;
+        head_[id] = next_[id] = prev_[id] = kNone;
+        return id;
+    }
+    void destroy(int32_t id) { alive[id] = 0; free_.push_back(id); }
+    void clear()
+    {
+        centre.clear(); radius.clear(); cost.clear(); heur.clear(); parent.clear(); kd_slot.clear();
+        alive.clear(); on_best.clear(); condemned.clear(); head_.clear(); next_.clear(); prev_.clear(); free_.clear();
+    }
+    size_t capacity() const { return centre.size(); }
+
+    void attach(int32_t child, int32_t to)
+    {
+        parent[child] = to;
+        prev_[child] = kNone;
+        next_[child] = head_[to];
+        if (head_[to] != kNone) prev_[head_[to]] = child;
+        head_[to] = child;
+    }
+    // takes `child` out of its parent's sibling list (no-op for a parentless sphere); the parent field becomes kNone
+    void detach(int32_t child)
+    {
+        const int32_t p = parent[child];
+        if (p == kNone) return;
+        if (prev_[child] != kNone) next_[prev_[child]] = next_[child];
+        else if (head_[p] == child) head_[p] = next_[child];
+        if (next_[child] != kNone) prev_[next_[child]] = prev_[child];
+        prev_[child] = next_[child] = kNone;
+        parent[child] = kNone;
+    }
+    // the parent link alone (the child stays listed under its old parent until that one is swept): resetRoot
+    void forget_parent(int32_t child) { detach(child); }
+    void children_of(int32_t id, std::vector<int32_t> &out) const
+    {
+        out.clear();
+        for (int32_t c = head_[id]; c != kNone; c = next_[c]) out.push_back(c);
+    }
+    int32_t first_child(int32_t id) const { return head_[id]; }
+    int32_t next_sibling(int32_t id) const { return next_[id]; }
+    // is `a` strictly above `below` (reachable from parent(below) upwards)?
+    bool above_parent_of(int32_t a, int32_t below) const
+    {
+        for (int32_t p = parent[below]; p != kNone; p = parent[p]) if (p == a) return true;
+        return false;
+    }
+private:
+    std::vector<int32_t> head_, next_, prev_, free_;
+};
+
+}  // namespace detail
+
 class SafeRegionRrtStar {
 public:
-    using NodePtr = CorridorNode *;
     static constexpr double kInf = 9999999.0;       // data_type.h:6
 
-    explicit SafeRegionRrtStar(int64_t cloud_capacity = 1 << 20, int device = 0) : map_(cloud_capacity, device), eng_(0) {}
-    ~SafeRegionRrtStar() { treeDestruct(); delete best_end_owned_; delete root_owned_; }
+    explicit SafeRegionRrtStar(int64_t cloud_capacity = 1 << 20, int device = 0) : map_(cloud_capacity, device), rng_(0) {}
+    ~SafeRegionRrtStar() { drop_tree(); }
     SafeRegionRrtStar(const SafeRegionRrtStar &) = delete;
     SafeRegionRrtStar &operator=(const SafeRegionRrtStar &) = delete;
 
-    // corridor_finder.cpp:17-23
+    // ---- configuration (corridor_finder.cpp:17-99) ----
     void setParam(double safety_margin, double search_margin, double max_radius, double sample_range)
     {
         safety_margin_ = safety_margin; search_margin_ = search_margin; max_radius_ = max_radius; sample_range_ = sample_range;
-        syncMap();
+        push_params();
     }
-    // :25-41
     void reset()
     {
-        treeDestruct();
-        NodeList.clear(); EndList.clear(); invalidSet.clear(); PathList.clear();
-        delete best_end_owned_; delete root_owned_;
-        best_end_ptr = best_end_owned_ = new CorridorNode();
-        root_node = root_owned_ = new CorridorNode();
-        path_exist_status = true; inform_status = false; global_navi_status = false;
-        best_distance = kInf;
+        drop_tree();
+        goal_ids_.clear(); route_.clear();
+        root_ = best_goal_ = kNone;
+        path_exists_ = true; informed_ = false; reached_commit_ = false;
+        best_cost_ = kInf;
     }
-    // :43-50
     void setStartPt(const Vec3 &startPt, const Vec3 &endPt)
     {
-        start_pt = startPt; end_pt = endPt;
-        x_in_lo = start_pt.x - sample_range_; x_in_hi = start_pt.x + sample_range_;
-        y_in_lo = start_pt.y - sample_range_; y_in_hi = start_pt.y + sample_range_;
-        syncMap();
+        start_ = startPt; goal_ = endPt;
+        near_x_ = { start_.x - sample_range_, start_.x + sample_range_ };
+        near_y_ = { start_.y - sample_range_, start_.y + sample_range_ };
+        push_params();
     }
-    // :52-91
     void setPt(const Vec3 &startPt, const Vec3 &endPt, double xl, double xh, double yl, double yh, double zl, double zh,
                double local_range, int max_iter, double sample_portion, double goal_portion)
     {
-        start_pt = startPt; end_pt = endPt;
-        x_l = xl; x_h = xh; y_l = yl; y_h = yh; z_l = zl; z_h = zh;
-        z_lo = z_l + safety_margin_; z_hi = z_h;
-        x_in_lo = start_pt.x - sample_range_; x_in_hi = start_pt.x + sample_range_;    // uses the OLD sample_range, as the reference does
-        y_in_lo = start_pt.y - sample_range_; y_in_hi = start_pt.y + sample_range_;
-        min_distance = std::sqrt(std::pow(start_pt.x - end_pt.x, 2) + std::pow(start_pt.y - end_pt.y, 2) + std::pow(start_pt.z - end_pt.z, 2));
-        updateEllipsoid(end_pt, (start_pt + end_pt) / 2.0);
+        start_ = startPt; goal_ = endPt;
+        box_x_ = { xl, xh }; box_y_ = { yl, yh }; box_z_ = { zl, zh };
+        sample_z_ = { zl + safety_margin_, zh };
+        // the window around the start still uses the sampling range of the PREVIOUS call, as the reference's does (:64-68 before :87)
+        near_x_ = { start_.x - sample_range_, start_.x + sample_range_ };
+        near_y_ = { start_.y - sample_range_, start_.y + sample_range_ };
+        direct_ = std::sqrt(std::pow(start_.x - goal_.x, 2) + std::pow(start_.y - goal_.y, 2) + std::pow(start_.z - goal_.z, 2));
+        aim_ellipsoid(goal_, (start_ + goal_) / 2.0);
         sample_range_ = local_range;
-        max_samples = max_iter;
-        inlier_ratio = sample_portion;
-        goal_ratio = goal_portion;
-        syncMap();
+        max_samples_ = max_iter;
+        near_share_ = sample_portion;
+        goal_share_ = goal_portion;
+        push_params();
     }
-    // :93-99.  pcl::PointXYZ records are 16 bytes; build_index = build the cell index (static clouds)
+    // pcl::PointXYZ records are 16 bytes; build_index = build the cell index (static clouds)
     void setInput(const void *points, int64_t n, int64_t stride_bytes = 16, bool build_index = true)
     {
         map_.setInput(points, n, stride_bytes, build_index);
     }
 
-    bool checkTrajPtCol(const Vec3 &pt) { return radiusSearch(pt) < 0.0; }                 // :412-416
-    std::pair<std::vector<Vec3>, std::vector<double>> getPath() const { return { Path, Radius }; }
-    const std::vector<NodePtr> &getTree() const { return NodeList; }
-    bool getPathExistStatus() const { return path_exist_status; }
-    bool getGlobalNaviStatus() const { return global_navi_status; }
-    ObstacleMap &obstacleMap() { return map_; }
-    uint64_t inflationQueries() const { return n_inflate_; }
-    // samples evaluated per GPU round trip in Expansion/Refine (1 = the reference's one-by-one loop)
-    void setSpeculation(int k) { spec_k_ = std::max(1, std::min(k, 256)); }
-    uint64_t speculativeHits() const { return n_spec_hit_; }
-    uint64_t speculativeFallbacks() const { return n_spec_miss_; }
-    uint64_t expansionLaunches() const { return n_launch_; }
-    uint64_t repairBatches() const { return n_repair_batches_; }      // GPU round trips of treeRepair: two per pass (was two per neighbour)
-    void setFusedExpansion(bool on) { fused_ok_ = on; }          // off = nearest / inflation / range as three batched launches
-
-    // :226-270
-    void resetRoot(const Vec3 &target_coord)
+    // ---- queries ----
+    bool checkTrajPtCol(const Vec3 &pt) { return clearance(pt) < 0.0; }                     // :412-416
+    std::pair<std::vector<Vec3>, std::vector<double>> getPath() const { return { path_centres_, path_radii_ }; }
+    std::vector<CorridorNode> getTree() const
     {
-        NodePtr lstNode = PathList.front();
-        if (getDis(lstNode->coord, target_coord) < lstNode->radius) { global_navi_status = true; return; }
-        double cost_reduction = 0;
-        commit_root = target_coord;
-        std::vector<NodePtr> cutList;
-        for (auto n : NodeList) n->best = false;
-        bool delete_root = false;
-        for (auto n : PathList) {
-            if (!delete_root && getDis(n->coord, target_coord) < (n->radius - 0.1)) {
-                delete_root = true;
-                n->best = true;
-                n->preNode_ptr = nullptr;
-                cost_reduction = n->g;
-                root_node = n;
+        std::vector<int32_t> where(T_.capacity(), -1);
+        for (size_t i = 0; i < order_.size(); i++) where[(size_t)order_[i]] = (int32_t)i;
+        std::vector<CorridorNode> out(order_.size());
+        for (size_t i = 0; i < order_.size(); i++) {
+            const int32_t id = order_[i];
+            out[i].coord = T_.centre[id]; out[i].radius = T_.radius[id]; out[i].g = T_.cost[id]; out[i].f = T_.heur[id];
+            out[i].valid = T_.alive[id] != 0; out[i].best = T_.on_best[id] != 0;
+            out[i].parent = T_.parent[id] == kNone ? -1 : where[(size_t)T_.parent[id]];
+        }
+        return out;
+    }
+    size_t treeSize() const { return order_.size(); }
+    bool getPathExistStatus() const { return path_exists_; }
+    bool getGlobalNaviStatus() const { return reached_commit_; }
+    ObstacleMap &obstacleMap() { return map_; }
+    uint64_t inflationQueries() const { return n_clearance_; }
+    // samples evaluated per GPU round trip in Expansion / Refine (1 = the reference's one-by-one loop)
+    void setSpeculation(int k) { ahead_ = std::max(1, std::min(k, 256)); }
+    uint64_t speculativeHits() const { return n_replayed_; }
+    uint64_t speculativeFallbacks() const { return n_restarts_; }
+    uint64_t expansionLaunches() const { return n_fused_launches_; }
+    uint64_t repairBatches() const { return n_repair_trips_; }        // GPU round trips of the repair pass: two per pass
+    void setFusedExpansion(bool on) { fused_ = on; }                  // off = nearest / clearance / range as three batched launches
+
+    // ---- corridor_finder.cpp:226-270: the drone has committed to `target`; the sphere of the current route that holds it
+    // becomes the root, everything between it and the old root is cut ----
+    void resetRoot(const Vec3 &target)
+    {
+        const int32_t tip = route_.front();
+        if (dist(T_.centre[tip], target) < T_.radius[tip]) { reached_commit_ = true; return; }
+        committed_ = target;
+        for (int32_t id : order_) T_.on_best[id] = 0;
+        double spent = 0;
+        bool found = false;
+        std::vector<int32_t> behind;
+        for (int32_t id : route_) {                                   // goal end first
+            if (!found) {
+                if (dist(T_.centre[id], target) < (T_.radius[id] - 0.1)) {
+                    found = true;
+                    T_.on_best[id] = 1;
+                    T_.forget_parent(id);
+                    spent = T_.cost[id];
+                    root_ = id;
+                }
                 continue;
             }
-            if (delete_root) { n->best = false; n->valid = false; cutList.push_back(n); }
+            T_.alive[id] = 0;
+            behind.push_back(id);
         }
-        solutionUpdate(cost_reduction, target_coord);
-        for (auto n : cutList) { invalidSet.push_back(n); clearBranchW(n); }
-        removeInvalid();
+        rebase_costs(spent, target);
+        for (int32_t id : behind) { note_condemned(id); condemn_below(id, /*spare_best=*/true); }
+        sweep();
     }
 
-    // :704-763 -- `iterations` replaces the wall-clock limit (and is capped by max_samples like the reference's loop)
+    // ---- :704-763 -- `iterations` replaces the wall-clock limit (capped by max_samples like the reference's loop) ----
     void SafeRegionExpansion(int64_t iterations)
     {
-        kdTree_ = kd_create(3);
-        if (!kdTree_) throw std::runtime_error(std::string("kd_create: ") + pct_last_error());
-        commit_root = start_pt;
-        root_node = new CorridorNode(start_pt, (float)radiusSearch(start_pt), 0.0f, (float)min_distance);
-        recordNode(root_node);
-        insertKd(root_node);
-        const int64_t limit = std::min<int64_t>(iterations, max_samples);
-        growMany(limit, false);
-        removeInvalid();
-        tracePath();
+        kd_ = kd_create(3);
+        if (!kd_) throw std::runtime_error(std::string("kd_create: ") + pct_last_error());
+        committed_ = start_;
+        root_ = T_.create(start_, (float)clearance(start_), 0.0f, (float)direct_);
+        order_.push_back(root_);
+        kd_add(root_);
+        grow(std::min<int64_t>(iterations, max_samples_), false);
+        sweep();
+        choose_route();
     }
-    // :765-815
+    // ---- :765-815 ----
     void SafeRegionRefine(int64_t iterations)
     {
-        growMany(iterations, true);
-        removeInvalid();
-        tracePath();
+        grow(iterations, true);
+        sweep();
+        choose_route();
     }
-    // :817-936 (no time limit: the pass loop ends on its own conditions)
+    // ---- :817-936: a new cloud has arrived; re-measure the route's spheres and cut what no longer holds.  The reference asks
+    // checkRadius sphere by sphere (:835); the radii depend only on the centres and the cloud, so each pass is one batched
+    // inflation whose answers the per-sphere logic then consumes in the reference's order. ----
     void SafeRegionEvaluate()
     {
-        if (!path_exist_status) return;
-        std::vector<std::pair<Vec3, double>> fail_node_list;
-        while (true) {
-            // The reference calls checkRadius node by node (:835); the radii only depend on the node coordinates and the
-            // cloud, so the whole pass is one batched inflation here and the per-node logic below consumes the results.
-            std::vector<double> coords;
-            std::vector<int> slot(PathList.size(), -1);
-            for (size_t i = 0; i < PathList.size(); i++)
-                if (PathList[i]->preNode_ptr != nullptr) {
-                    slot[i] = (int)(coords.size() / 3);
-                    coords.push_back(PathList[i]->coord.x); coords.push_back(PathList[i]->coord.y); coords.push_back(PathList[i]->coord.z);
-                }
-            std::vector<double> radii(coords.size() / 3);
-            if (!radii.empty()) { map_.checkRadiusBatch(coords.data(), (int64_t)radii.size(), radii.data()); n_inflate_ += radii.size(); }
-
-            for (size_t i = 0; i < PathList.size(); i++) {
-                NodePtr ptr = PathList[i];
-                NodePtr pre_ptr = ptr->preNode_ptr;
-                if (pre_ptr == nullptr) continue;
-                const double update_radius = radii[slot[i]];
-                const int ret = checkNodeUpdate(update_radius, ptr->radius);
-                const double old_radius = ptr->radius;
-                ptr->radius = (float)update_radius;
-                syncNodeAux(ptr);
-                if (ret == -1) {
-                    ptr->valid = false;
-                    invalidSet.push_back(ptr);
-                    clearBranchS(ptr);
-                    fail_node_list.push_back({ ptr->coord, old_radius });
-                } else if (checkNodeRelation(getDis(ptr->coord, pre_ptr->coord), ptr, pre_ptr) != -1) {
-                    if (ptr->valid) {
-                        ptr->valid = false;
-                        invalidSet.push_back(ptr);
-                        clearBranchS(ptr);
-                        fail_node_list.push_back({ ptr->coord, old_radius });
+        if (!path_exists_) return;
+        std::vector<std::pair<Vec3, double>> broken;                  // (centre, radius before the update) of every sphere cut here
+        std::vector<double> xyz, fresh;
+        std::vector<int32_t> kids;
+        for (;;) {
+            xyz.clear();
+            for (int32_t id : route_)
+                if (T_.parent[id] != kNone) { xyz.push_back(T_.centre[id].x); xyz.push_back(T_.centre[id].y); xyz.push_back(T_.centre[id].z); }
+            fresh.assign(xyz.size() / 3, 0.0);
+            if (!fresh.empty()) { map_.checkRadiusBatch(xyz.data(), (int64_t)fresh.size(), fresh.data()); n_clearance_ += fresh.size(); }
+            size_t k = 0;
+            for (int32_t id : route_) {
+                const int32_t up = T_.parent[id];
+                if (up == kNone) continue;
+                const double now = fresh[k++], before = T_.radius[id];
+                const int verdict = judge_radius(now, before);
+                T_.radius[id] = (float)now;
+                kd_refresh(id);
+                if (verdict < 0) {
+                    T_.alive[id] = 0;
+                    note_condemned(id);
+                    condemn_below(id, false);
+                    broken.push_back({ T_.centre[id], before });
+                } else if (overlap(dist(T_.centre[id], T_.centre[up]), id, up) != kLinked) {
+                    if (T_.alive[id]) {
+                        T_.alive[id] = 0;
+                        note_condemned(id);
+                        condemn_below(id, false);
+                        broken.push_back({ T_.centre[id], before });
                     }
                 } else {
-                    const std::vector<NodePtr> childList = ptr->nxtNode_ptr;
-                    for (auto child : childList)
-                        if (checkNodeRelation(getDis(ptr->coord, child->coord), ptr, child) != -1 && child->valid) {
-                            child->valid = false;
-                            invalidSet.push_back(child);
-                            clearBranchS(child);
-                            fail_node_list.push_back({ child->coord, (double)child->radius });
+                    T_.children_of(id, kids);
+                    for (int32_t c : kids)
+                        if (overlap(dist(T_.centre[id], T_.centre[c]), id, c) != kLinked && T_.alive[c]) {
+                            T_.alive[c] = 0;
+                            note_condemned(c);
+                            condemn_below(c, false);
+                            broken.push_back({ T_.centre[c], (double)T_.radius[c] });
                         }
                 }
             }
-            bool isBreak = true;
-            for (auto p : PathList) isBreak = isBreak && p->valid;
-            if (isBreak) break;
-
-            std::vector<NodePtr> feasibleEndList;
-            for (auto e : EndList)
-                if (e->valid && checkEnd(e)) feasibleEndList.push_back(e);
-            EndList = feasibleEndList;
-            if (feasibleEndList.empty()) {
-                path_exist_status = false; inform_status = false; best_distance = kInf;
-                break;
-            }
-            best_end_ptr = feasibleEndList[0];
-            double best_cost = kInf;
-            for (auto n : feasibleEndList) {
-                const double cost = n->g + getDis(n->coord, end_pt) + getDis(root_node->coord, commit_root);
-                if (cost < best_cost) { best_end_ptr = n; best_cost = cost; best_distance = best_cost; }
-            }
-            PathList.clear();
-            for (NodePtr p = best_end_ptr; p != nullptr; p = p->preNode_ptr) PathList.push_back(p);
+            bool intact = true;
+            for (int32_t id : route_) intact = intact && T_.alive[id];
+            if (intact) break;
+            std::vector<int32_t> usable;
+            for (int32_t e : goal_ids_) if (T_.alive[e] && touches_goal(e)) usable.push_back(e);
+            goal_ids_ = usable;
+            if (usable.empty()) { path_exists_ = false; informed_ = false; best_cost_ = kInf; break; }
+            pick_cheapest(usable);
+            route_.clear();
+            for (int32_t p = best_goal_; p != kNone; p = T_.parent[p]) route_.push_back(p);
         }
-        removeInvalid();
-        treeRepair(fail_node_list);
-        tracePath();
+        sweep();
+        repair_around(broken);
+        choose_route();
     }
 
 private:
-    // ---- geometry helpers (:101-111) ----
-    static double getDis(const Vec3 &a, const Vec3 &b)
+    static constexpr int32_t kNone = detail::SphereArena::kNone;
+    // how two spheres relate (corridor_finder.cpp:439-454): one inside the other / overlapping enough to fly through / neither
+    static constexpr int kInside = 1, kLinked = -1, kApart = 0;
+
+    static double dist(const Vec3 &a, const Vec3 &b)                  // :101-105, with pow() as there
     {
         return std::sqrt(std::pow(a.x - b.x, 2) + std::pow(a.y - b.y, 2) + std::pow(a.z - b.z, 2));
     }
-    void syncMap()
+    int overlap(double d, int32_t a, int32_t b) const
+    {
+        if ((d + T_.radius[b]) == T_.radius[a]) return kInside;
+        if ((d + 0.1) < 0.95 * (T_.radius[a] + T_.radius[b])) return kLinked;
+        return kApart;
+    }
+    int judge_radius(double now, double before) const                 // :661-669
+    {
+        if (now < safety_margin_) return -1;
+        return now < before ? 0 : 1;
+    }
+    bool touches_goal(int32_t id) const { return dist(T_.centre[id], goal_) + 0.1 < T_.radius[id]; }        // :418-426
+    bool chain_holds(int32_t tip) const                               // :685-702: alive all the way up to a sphere that holds the root
+    {
+        for (int32_t p = tip; p != kNone; p = T_.parent[p]) {
+            if (!T_.alive[p]) return false;
+            if (dist(T_.centre[p], root_centre()) < T_.radius[p]) return true;
+        }
+        return false;
+    }
+    Vec3 root_centre() const { return root_ == kNone ? Vec3() : T_.centre[root_]; }
+    double route_cost(int32_t tip) const { return T_.cost[tip] + dist(T_.centre[tip], goal_) + dist(root_centre(), committed_); }
+
+    void push_params()
     {
         map_.setParam(safety_margin_, search_margin_, max_radius_, sample_range_);
-        const double s[3] = { start_pt.x, start_pt.y, start_pt.z };
+        const double s[3] = { start_.x, start_.y, start_.z };
         map_.setStartPt(s);
     }
-    // kd_* return NULL on a device failure (and kd_nearest* on an empty tree): surface it as an exception the C ABI wrapper
-    // (csrc/corridor.cpp guarded()) turns into an error code, instead of dereferencing it
+    // kd_* return NULL on a device failure (and kd_nearest* on an empty tree): an exception the C ABI wrapper
+    // (csrc/corridor.cpp guarded()) turns into an error code, instead of a NULL dereference
     static kdres *must(kdres *r, const char *what)
     {
         if (!r) throw std::runtime_error(std::string(what) + " returned no result set: " + pct_last_error());
         return r;
     }
-    double radiusSearch(const Vec3 &p)                      // :113-133 -> HIP inflation
+    static void *tag(int32_t id) { return reinterpret_cast<void *>((intptr_t)id + 1); }
+    static int32_t untag(void *p) { return (int32_t)(reinterpret_cast<intptr_t>(p) - 1); }
+
+    double clearance(const Vec3 &p)                                   // radiusSearch (:113-133) on the HIP inflation path
     {
         const double q[3] = { p.x, p.y, p.z };
-        n_inflate_++;
+        n_clearance_++;
         return map_.radiusSearch(q);
     }
-    void updateEllipsoid(const Vec3 &toward, const Vec3 &centre)         // :77-85, :285-295
+
+    // ---- sampling (:77-85, :272-383) ----
+    void aim_ellipsoid(const Vec3 &toward, const Vec3 &centre)
     {
-        translation_inf = centre;
-        const Vec3 downward(0, 0, -1);
-        const Vec3 xtf = (toward - translation_inf).normalized();
-        const Vec3 ytf = xtf.cross(downward).normalized();
-        const Vec3 ztf = xtf.cross(ytf);
-        rot_c0 = xtf; rot_c1 = ytf; rot_c2 = ztf;
+        ell_centre_ = centre;
+        const Vec3 down(0, 0, -1);
+        ell_u_ = (toward - ell_centre_).normalized();
+        ell_v_ = ell_u_.cross(down).normalized();
+        ell_w_ = ell_u_.cross(ell_v_);
     }
-    void solutionUpdate(double cost_reduction, const Vec3 &target)       // :272-296
+    void rebase_costs(double spent, const Vec3 &target)               // solutionUpdate
     {
-        for (auto n : NodeList) n->g = (float)((double)n->g - cost_reduction);     // float -= double, as written in the reference
-        min_distance = getDis(target, end_pt);
-        updateEllipsoid(target, (target + end_pt) / 2.0);
-        best_distance -= cost_reduction;
+        for (int32_t id : order_) T_.cost[id] = (float)((double)T_.cost[id] - spent);      // float -= double, as written there
+        direct_ = dist(target, goal_);
+        aim_ellipsoid(target, (target + goal_) / 2.0);
+        best_cost_ -= spent;
     }
-    void updateHeuristicRegion(NodePtr update_end_node)                  // :298-331
+    void tighten_ellipsoid(int32_t tip)                               // updateHeuristicRegion
     {
-        const double update_cost = update_end_node->g + getDis(update_end_node->coord, end_pt) + getDis(root_node->coord, commit_root);
-        if (update_cost < best_distance) {
-            best_distance = update_cost;
-            elli_l = best_distance;
-            elli_s = std::sqrt(best_distance * best_distance - min_distance * min_distance);
-            if (inform_status) for (auto p : NodeList) p->best = false;
-            for (NodePtr p = update_end_node; p != nullptr; p = p->preNode_ptr) p->best = true;
-            best_end_ptr = update_end_node;
-            sample_epoch_++;          // the sampling ellipsoid changed
-        }
+        const double c = route_cost(tip);
+        if (!(c < best_cost_)) return;
+        best_cost_ = c;
+        ell_long_ = best_cost_;
+        ell_short_ = std::sqrt(best_cost_ * best_cost_ - direct_ * direct_);
+        if (informed_) for (int32_t id : order_) T_.on_best[id] = 0;
+        for (int32_t p = tip; p != kNone; p = T_.parent[p]) T_.on_best[p] = 1;
+        best_goal_ = tip;
+        sampler_version_++;
     }
-    Vec3 genSample()                                                     // :333-383
+    Vec3 draw()
     {
-        const double bias = eng_.uniform(0.0, 1.0);
-        if (bias <= goal_ratio) return end_pt;
+        const double u = rng_.uniform(0.0, 1.0);
+        if (u <= goal_share_) return goal_;
         Vec3 pt;
-        if (!inform_status) {
-            if (bias > goal_ratio && bias <= (goal_ratio + inlier_ratio)) {
-                pt.x = eng_.uniform(x_in_lo, x_in_hi); pt.y = eng_.uniform(y_in_lo, y_in_hi); pt.z = eng_.uniform(z_lo, z_hi);
-            } else {
-                pt.x = eng_.uniform(x_l, x_h); pt.y = eng_.uniform(y_l, y_h); pt.z = eng_.uniform(z_lo, z_hi);
-            }
-        } else {
-            const double us = eng_.uniform(0.0, 1.0), vs = eng_.uniform(0.0, 1.0), phis = eng_.uniform(0.0, 2 * M_PI);
-            const double as = elli_l / 2.0 * std::cbrt(us), bs = elli_s / 2.0 * std::cbrt(us);
-            const double thetas = std::acos(1 - 2 * vs);
-            const Vec3 e(as * std::sin(thetas) * std::cos(phis), bs * std::sin(thetas) * std::sin(phis), bs * std::cos(thetas));
-            pt = rot_c0 * e.x + rot_c1 * e.y + rot_c2 * e.z + translation_inf;
-            pt.x = std::min(std::max(pt.x, x_l), x_h);
-            pt.y = std::min(std::max(pt.y, y_l), y_h);
-            pt.z = std::min(std::max(pt.z, z_l), z_h);
+        if (!informed_) {
+            const bool near = u > goal_share_ && u <= (goal_share_ + near_share_);
+            const auto &bx = near ? near_x_ : box_x_, &by = near ? near_y_ : box_y_;
+            pt.x = rng_.uniform(bx.first, bx.second);
+            pt.y = rng_.uniform(by.first, by.second);
+            pt.z = rng_.uniform(sample_z_.first, sample_z_.second);
+            return pt;
         }
+        const double us = rng_.uniform(0.0, 1.0), vs = rng_.uniform(0.0, 1.0), phi = rng_.uniform(0.0, 2 * M_PI);
+        const double a = ell_long_ / 2.0 * std::cbrt(us), b = ell_short_ / 2.0 * std::cbrt(us);
+        const double theta = std::acos(1 - 2 * vs);
+        const Vec3 e(a * std::sin(theta) * std::cos(phi), b * std::sin(theta) * std::sin(phi), b * std::cos(theta));
+        pt = ell_u_ * e.x + ell_v_ * e.y + ell_w_ * e.z + ell_centre_;
+        pt.x = std::min(std::max(pt.x, box_x_.first), box_x_.second);
+        pt.y = std::min(std::max(pt.y, box_y_.first), box_y_.second);
+        pt.z = std::min(std::max(pt.z, box_z_.first), box_z_.second);
         return pt;
     }
-    NodePtr findNearstVertex(const Vec3 &pt)                             // :428-437
+
+    // ---- the kd tree over the spheres' centres ----
+    void kd_add(int32_t id)
+    {
+        float pos[3] = { (float)T_.centre[id].x, (float)T_.centre[id].y, (float)T_.centre[id].z };
+        T_.kd_slot[id] = kdx_size(kd_);
+        if (kd_insertf(kd_, pos, tag(id)) != 0) throw std::runtime_error(std::string("kd_insertf: ") + pct_last_error());
+        kd_refresh(id);
+    }
+    // what the fused expansion kernel's steer step reads for a sphere: fp64 centre, float radius (widened)
+    void kd_refresh(int32_t id)
+    {
+        const int32_t slot = T_.kd_slot[id];
+        if (slot < 0 || slot >= kdx_size(kd_) || kdx_node_data(kd_, slot) != tag(id)) return;
+        const double aux[4] = { T_.centre[id].x, T_.centre[id].y, T_.centre[id].z, (double)T_.radius[id] };
+        kdx_set_node_aux(kd_, slot, aux);
+    }
+    int32_t nearest_sphere(const Vec3 &pt)                            // :428-437
     {
         float pos[3] = { (float)pt.x, (float)pt.y, (float)pt.z };
-        kdres *nearest = must(kd_nearestf(kdTree_, pos), "kd_nearestf");
-        NodePtr n = (NodePtr)kd_res_item_data(nearest);
-        kd_res_free(nearest);
-        return n;
+        kdres *r = must(kd_nearestf(kd_, pos), "kd_nearestf");
+        void *d = kd_res_item_data(r);
+        kd_res_free(r);
+        return d ? untag(d) : kNone;
     }
-    NodePtr genNewNode(const Vec3 &pt_sample, NodePtr nearest)           // :385-410
+    Vec3 steer(const Vec3 &sample, int32_t from) const                // the first half of genNewNode (:387-404)
     {
-        const Vec3 center = steer(pt_sample, nearest);
-        const double radius_ = radiusSearch(center);
-        const double h_dis_ = getDis(center, end_pt);
-        return new CorridorNode(center, (float)radius_, (float)kInf, (float)h_dis_);
-    }
-    bool checkEnd(NodePtr p) const { return getDis(p->coord, end_pt) + 0.1 < p->radius; }       // :418-426
-    static int checkNodeRelation(double dis, NodePtr n1, NodePtr n2)                             // :439-454
-    {
-        if ((dis + n2->radius) == n1->radius) return 1;
-        if ((dis + 0.1) < 0.95 * (n1->radius + n2->radius)) return -1;
-        return 0;
-    }
-    int checkNodeUpdate(double new_radius, double old_radius) const                             // :661-669
-    {
-        if (new_radius < safety_margin_) return -1;
-        if (new_radius < old_radius) return 0;
-        return 1;
-    }
-    static bool isSuccessor(NodePtr cur, NodePtr near)                                          // :670-683
-    {
-        for (NodePtr p = near->preNode_ptr; p != nullptr; p = p->preNode_ptr) if (p == cur) return true;
-        return false;
-    }
-    bool checkValidEnd(NodePtr endPtr) const                                                    // :685-702
-    {
-        for (NodePtr p = endPtr; p != nullptr; p = p->preNode_ptr) {
-            if (!p->valid) return false;
-            if (getDis(p->coord, root_node->coord) < p->radius) return true;
+        const Vec3 &c = T_.centre[from];
+        const double d = dist(c, sample);
+        if (d > T_.radius[from]) {
+            const double t = T_.radius[from] / d;
+            return Vec3(c.x + (sample.x - c.x) * t, c.y + (sample.y - c.y) * t, c.z + (sample.z - c.z) * t);
         }
-        return false;
+        return sample;
     }
-    void insertKd(NodePtr n)
+    // the kd tree sees float-narrowed centres and queries
+    static double kd_d2(const Vec3 &c, const float q[3])
     {
-        float pos[3] = { (float)n->coord.x, (float)n->coord.y, (float)n->coord.z };
-        n->kd_index = kdx_size(kdTree_);
-        if (kd_insertf(kdTree_, pos, n) != 0) throw std::runtime_error(std::string("kd_insertf: ") + pct_last_error());
-        syncNodeAux(n);
-    }
-    // what the fused expansion kernel's steer step reads for this node: fp64 centre, float radius (widened)
-    void syncNodeAux(NodePtr n)
-    {
-        if (n->kd_index < 0 || n->kd_index >= kdx_size(kdTree_) || kdx_node_data(kdTree_, n->kd_index) != (void *)n) return;
-        const double aux[4] = { n->coord.x, n->coord.y, n->coord.z, (double)n->radius };
-        kdx_set_node_aux(kdTree_, n->kd_index, aux);
-    }
-    void recordNode(NodePtr n) { NodeList.push_back(n); }                                       // :569-573
-
-    // one iteration of the Expansion (:719-756) / Refine (:772-808) loop body
-    void growOnce(bool refine) { growWithSample(genSample(), refine); }
-    void growWithSample(const Vec3 &pt_sample, bool refine)
-    {
-        NodePtr nearest = findNearstVertex(pt_sample);
-        if (nearest == nullptr || !nearest->valid) return;
-        NodePtr fresh = genNewNode(pt_sample, nearest);
-        finishGrow(fresh, nearest, refine, nullptr);
-    }
-    // everything after genNewNode; presults != nullptr = the neighbourhood set was prepared by the caller
-    void finishGrow(NodePtr fresh, NodePtr nearest, bool refine, kdres *presults)
-    {
-        if (fresh->coord.z < z_l || fresh->radius < safety_margin_) { if (presults) kd_res_free(presults); discarded_.push_back(fresh); return; }
-        treeRewire(fresh, nearest, presults);
-        if (!fresh->valid) { discarded_.push_back(fresh); return; }
-        if (checkEnd(fresh)) {
-            if (!inform_status) { best_end_ptr = fresh; sample_epoch_++; }      // genSample switches to the ellipsoid from now on
-            EndList.push_back(fresh);
-            if (refine) updateHeuristicRegion(fresh);
-            inform_status = true;
-        }
-        insertKd(fresh);
-        recordNode(fresh);
-        treePrune(fresh);
-        if ((int)invalidSet.size() >= cach_size) removeInvalid();
-    }
-
-    static double kdDist2(const Vec3 &node_coord, const float q[3])      // the kd tree sees float-narrowed node positions and queries
-    {
-        const double dx = (double)(float)node_coord.x - (double)q[0], dy = (double)(float)node_coord.y - (double)q[1],
-                     dz = (double)(float)node_coord.z - (double)q[2];
+        const double dx = (double)(float)c.x - (double)q[0], dy = (double)(float)c.y - (double)q[1], dz = (double)(float)c.z - (double)q[2];
         double s = dx * dx;
         s = s + dy * dy;
         s = s + dz * dz;
         return s;
     }
 
-    void growMany(int64_t iterations, bool refine)
+    // ---- invalidation bookkeeping.  The reference pushes a pointer per invalidation and sweeps when ten have piled up (:8, :759);
+    // here a sphere is queued once (condemned flag) and the EVENTS are counted, so the sweeps happen at the same moments. ----
+    void note_condemned(int32_t id)
+    {
+        condemn_events_++;
+        if (!T_.condemned[id]) { T_.condemned[id] = 1; doomed_.push_back(id); }
+    }
+    void condemn_below(int32_t top, bool spare_best)                  // clearBranchS (:151-159) / clearBranchW (:135-149)
+    {
+        walk_.clear();
+        walk_.push_back(top);
+        while (!walk_.empty()) {
+            const int32_t at = walk_.back();
+            walk_.pop_back();
+            for (int32_t c = T_.first_child(at); c != kNone; c = T_.next_sibling(c)) {
+                if (spare_best && T_.on_best[c]) continue;
+                if (T_.alive[c]) note_condemned(c);
+                T_.alive[c] = 0;
+                walk_.push_back(c);
+            }
+        }
+    }
+    // removeInvalid (:170-231): rebuild the kd tree from the surviving spheres (in list order: the tree's shape, and with it the
+    // order of range results, depends on it), recompute the goal-touching set, unhook and release the condemned ones
+    void sweep()
+    {
+        kd_version_++;
+        kd_clear(kd_);
+        size_t w = 0;
+        goal_ids_.clear();
+        for (int32_t id : order_) {
+            if (!T_.alive[id]) continue;
+            kd_add(id);
+            order_[w++] = id;
+            if (touches_goal(id)) goal_ids_.push_back(id);
+        }
+        order_.resize(w);
+        for (int32_t id : doomed_) T_.detach(id);
+        for (int32_t id : doomed_) {
+            for (int32_t c = T_.first_child(id); c != kNone;) {       // whatever still hangs here survives as a parentless sphere
+                const int32_t nxt = T_.next_sibling(c);
+                T_.detach(c);
+                c = nxt;
+            }
+            T_.destroy(id);
+        }
+        doomed_.clear();
+        condemn_events_ = 0;
+    }
+    void drop_tree()                                                  // :645-654
+    {
+        if (kd_) { kd_free(kd_); kd_ = nullptr; }
+        T_.clear();
+        order_.clear(); doomed_.clear();
+        condemn_events_ = 0;
+    }
+
+    // ---- accepting a candidate sphere: everything after genNewNode in the loop bodies (:728-756, :781-808) ----
+    void accept(const Vec3 &centre, double radius, int32_t nearest, bool refine, kdres *neighbourhood)
+    {
+        const float r = (float)radius;
+        if (centre.z < box_z_.first || r < safety_margin_) { if (neighbourhood) kd_res_free(neighbourhood); return; }
+        const int32_t id = T_.create(centre, r, (float)kInf, (float)dist(centre, goal_));
+        if (!wire_in(id, nearest, neighbourhood)) { T_.destroy(id); return; }
+        if (touches_goal(id)) {
+            if (!informed_) { best_goal_ = id; sampler_version_++; }  // draw() switches to the ellipsoid from now on
+            goal_ids_.push_back(id);
+            if (refine) tighten_ellipsoid(id);
+            informed_ = true;
+        }
+        kd_add(id);
+        order_.push_back(id);
+        const float through = T_.cost[id] + T_.heur[id];              // float + float, as in treePrune (:161-169)
+        if (through > best_cost_) { T_.alive[id] = 0; note_condemned(id); condemn_below(id, false); }
+        if (condemn_events_ >= sweep_after_) sweep();
+    }
+    // treeRewire (:457-567).  Returns false when some neighbour's sphere contains the candidate (it adds nothing).
+    bool wire_in(int32_t id, int32_t nearest, kdres *hits)
+    {
+        if (!hits) {
+            const float range = T_.radius[id] * 2.0f;
+            float pos[3] = { (float)T_.centre[id].x, (float)T_.centre[id].y, (float)T_.centre[id].z };
+            hits = must(kd_nearest_rangef(kd_, pos, range), "kd_nearest_rangef");
+        }
+        near_.clear();
+        bool swallowed = false;
+        for (; !kd_res_end(hits); kd_res_next(hits)) {
+            const int32_t nb = untag(kd_res_item_data(hits));
+            const double d = dist(T_.centre[nb], T_.centre[id]);
+            const int rel = overlap(d, nb, id);
+            near_.push_back({ nb, rel, (float)d });
+            if (rel == kInside) { swallowed = true; break; }
+        }
+        kd_res_free(hits);
+        if (swallowed) return false;
+        // cheapest parent among the linked neighbours, the nearest sphere being the one to beat (strict <, first wins)
+        int32_t up = nearest;
+        double cheapest = T_.cost[nearest] + dist(T_.centre[nearest], T_.centre[id]);
+        for (const auto &n : near_)
+            if (n.rel == kLinked) {
+                const double via = T_.cost[n.id] + (double)n.d;       // the distance went through a float field there (rel_dis)
+                if (via < cheapest) { cheapest = via; up = n.id; }
+            }
+        T_.cost[id] = (float)cheapest;
+        T_.attach(id, up);
+        // and the other way round: linked neighbours that get cheaper through the new sphere move under it
+        for (const auto &n : near_) {
+            if (n.rel != kLinked || !T_.alive[n.id]) continue;
+            const double via = dist(T_.centre[n.id], T_.centre[id]) + T_.cost[id];
+            if (!(via < T_.cost[n.id])) continue;
+            if (T_.above_parent_of(n.id, up)) continue;               // isSuccessor (:670-683): it sits above the new sphere's parent
+            T_.detach(n.id);
+            T_.cost[n.id] = (float)via;
+            T_.attach(n.id, id);
+        }
+        return true;
+    }
+
+    // ---- route selection (tracePath, :575-643) ----
+    void pick_cheapest(const std::vector<int32_t> &tips)
+    {
+        best_goal_ = tips[0];
+        double lowest = kInf;
+        for (int32_t t : tips) {
+            const double c = route_cost(t);
+            if (c < lowest) { best_goal_ = t; lowest = c; best_cost_ = c; }
+        }
+    }
+    void choose_route()
+    {
+        std::vector<int32_t> usable;
+        for (int32_t e : goal_ids_) if (chain_holds(e) && touches_goal(e) && T_.alive[e]) usable.push_back(e);
+        if (usable.empty()) {
+            path_exists_ = false; best_cost_ = kInf; informed_ = false;
+            goal_ids_.clear();
+            path_centres_ = { Vec3(1, 0, 0), Vec3(0, 1, 0), Vec3(0, 0, 1) };                // MatrixXd::Identity(3,3)
+            path_radii_ = { 0.0, 0.0, 0.0 };
+            return;
+        }
+        goal_ids_ = usable;
+        pick_cheapest(usable);
+        route_.clear();
+        for (int32_t p = best_goal_; p != kNone; p = T_.parent[p]) route_.push_back(p);
+        const size_t k = route_.size();
+        path_centres_.assign(k, Vec3());
+        path_radii_.assign(k, 0.0);
+        for (size_t i = 0; i < k; i++) { path_centres_[k - 1 - i] = T_.centre[route_[i]]; path_radii_[k - 1 - i] = T_.radius[route_[i]]; }
+        path_exists_ = true;
+    }
+
+    // ---- treeRepair (:938-1021), one batch per pass.  The reference asks, per broken sphere, one kd_nearest_rangef and then one
+    // radiusSearch per live neighbour -- each a launch + a host round trip here.  Neither the kd tree nor the cloud changes inside
+    // that loop (spheres are only marked; the sweep runs after it) and a clearance is a pure function of the centre, so: ONE launch
+    // finds the neighbourhood candidates of every broken sphere, ONE launch measures every sphere the loop could re-check, and the
+    // per-sphere logic then runs on the host in the reference's order with those answers. ----
+    void repair_around(const std::vector<std::pair<Vec3, double>> &broken)
+    {
+        const int K = (int)broken.size();
+        if (K == 0) { sweep(); return; }
+        const int32_t n0 = kdx_size(kd_);
+        const int cap = 256;
+        std::vector<float> posf((size_t)3 * K), range((size_t)K);
+        for (int i = 0; i < K; i++) {
+            const Vec3 &c = broken[(size_t)i].first;
+            posf[3 * (size_t)i] = (float)c.x; posf[3 * (size_t)i + 1] = (float)c.y; posf[3 * (size_t)i + 2] = (float)c.z;
+            range[(size_t)i] = (float)broken[(size_t)i].second * 2.0f;
+        }
+        std::vector<kdres *> sets((size_t)K, nullptr);
+        struct Release { std::vector<kdres *> &v; ~Release() { for (auto r : v) if (r) kd_res_free(r); } } release{ sets };
+        {
+            std::vector<uint32_t> ids((size_t)K * cap);
+            std::vector<int32_t> counts((size_t)K);
+            for (int b0 = 0; b0 < K; b0 += 1024) {                    // kdx batches hold at most 1024 queries
+                const int m = std::min(1024, K - b0);
+                const bool ok = kdx_range_candidates_batch(kd_, &posf[3 * (size_t)b0], &range[(size_t)b0], m, &ids[(size_t)b0 * cap], cap, &counts[(size_t)b0]) == 0;
+                n_repair_trips_++;
+                for (int i = b0; i < b0 + m; i++)
+                    sets[(size_t)i] = must(ok && counts[(size_t)i] >= 0 ? kdx_range_from_candidates(kd_, &posf[3 * (size_t)i], range[(size_t)i], &ids[(size_t)i * cap], counts[(size_t)i], n0)
+                                                                        : kd_nearest_rangef(kd_, &posf[3 * (size_t)i], range[(size_t)i]), "kd_nearest_rangef");
+            }
+        }
+        // every sphere the loop below may re-measure: in some broken sphere's neighbourhood, alive, neither the root nor a child of it
+        std::vector<int32_t> pending;
+        std::vector<int32_t> slot_of(T_.capacity(), -1);
+        for (int i = 0; i < K; i++) {
+            kdres *s = sets[(size_t)i];
+            for (kd_res_rewind(s); !kd_res_end(s); kd_res_next(s)) {
+                const int32_t id = untag(kd_res_item_data(s));
+                if (!T_.alive[id] || T_.parent[id] == root_ || id == root_ || slot_of[(size_t)id] >= 0) continue;
+                slot_of[(size_t)id] = (int32_t)pending.size();
+                pending.push_back(id);
+            }
+            kd_res_rewind(s);
+        }
+        std::vector<double> xyz(3 * pending.size()), measured(pending.size());
+        for (size_t k = 0; k < pending.size(); k++) {
+            const Vec3 &c = T_.centre[pending[k]];
+            xyz[3 * k] = c.x; xyz[3 * k + 1] = c.y; xyz[3 * k + 2] = c.z;
+        }
+        if (!pending.empty()) { map_.checkRadiusBatch(xyz.data(), (int64_t)pending.size(), measured.data()); n_repair_trips_++; }
+
+        std::vector<int32_t> kids;
+        for (int i = 0; i < K; i++) {
+            kdres *s = sets[(size_t)i];
+            while (!kd_res_end(s)) {
+                const int32_t id = untag(kd_res_item_data(s));
+                kd_res_next(s);
+                if (!T_.alive[id]) continue;
+                const int32_t up = T_.parent[id];
+                if (up == root_ || id == root_) continue;
+                double now;
+                if (slot_of[(size_t)id] >= 0) { now = measured[(size_t)slot_of[(size_t)id]]; n_clearance_++; }   // counted where the reference asks
+                else now = clearance(T_.centre[id]);
+                const int verdict = judge_radius(now, T_.radius[id]);
+                T_.radius[id] = (float)now;
+                kd_refresh(id);
+                if (verdict < 0) {
+                    if (T_.alive[id]) { T_.alive[id] = 0; note_condemned(id); condemn_below(id, false); }
+                    continue;
+                }
+                if (up == kNone) continue;     // the reference dereferences a NULL parent here; a parentless non-root sphere has nothing to re-check
+                if (overlap(dist(T_.centre[up], T_.centre[id]), up, id) != kLinked && T_.alive[up]) {
+                    T_.alive[up] = 0;
+                    note_condemned(up);
+                    condemn_below(up, false);
+                    continue;
+                }
+                T_.children_of(id, kids);
+                for (int32_t c : kids)
+                    if (overlap(dist(T_.centre[id], T_.centre[c]), id, c) != kLinked && T_.alive[c]) {
+                        T_.alive[c] = 0;
+                        note_condemned(c);
+                        condemn_below(c, false);
+                    }
+            }
+        }
+        sweep();
+    }
+
+    // ---- the sampling loops ----
+    void grow(int64_t iterations, bool refine)
     {
         int64_t done = 0;
         while (done < iterations) {
-            if (spec_k_ <= 1 && !fused_ok_) { growOnce(refine); done++; continue; }      // three single queries per iteration
+            if (ahead_ <= 1 && !fused_) { grow_one(draw(), refine); done++; continue; }      // three single queries per iteration
             // (with the fused kernel even K = 1 is one launch per iteration instead of three)
-            done += growBatch((int)std::min<int64_t>(std::max(spec_k_, 1), iterations - done), refine);
+            const int K = (int)std::min<int64_t>(std::max(ahead_, 1), iterations - done);
+            done += fused_ ? grow_fused(K, refine) : grow_staged(K, refine);
         }
     }
-
-    // Speculative batch: evaluate K samples against a snapshot of the tree with three batched GPU calls, then replay them
-    // in order.  A sample is replayed from the precomputed answers only if nothing an earlier sample of the batch did could
-    // have changed them; otherwise it takes the one-by-one path, and if the sampling distribution or the kd tree itself
-    // changed (path found / improved, removeInvalid rebuilt the tree) the rest of the batch is discarded and the generator
-    // is rewound, so the sequence of samples is exactly the sequential one.  Returns the number of samples consumed.
-    int growBatch(int K, bool refine) { return fused_ok_ ? growBatchFused(K, refine) : growBatchStaged(K, refine); }
-
-    // The same speculation with ONE launch per batch: kdx_expand_batch answers nearest node -> steer -> inflation ->
-    // neighbourhood candidates of every sample in a single kernel (the three stages of growBatchStaged are dependent, so
-    // staged they cost three launch + sync round trips).  When a sample's nearest node turns out to be one added earlier
-    // in the batch, the REST of the batch is re-evaluated against the tree as it is now -- one launch again, and the
-    // conflicting sample is then first in line and cannot conflict -- instead of walking that sample through three
-    // single queries.  Samples, acceptance order and results are exactly the sequential ones.
-    int growBatchFused(int K, bool refine)
+    void grow_one(const Vec3 &sample, bool refine)                     // one iteration of :719-756 / :772-808
     {
-        const uint64_t epoch0 = sample_epoch_, kd_epoch0 = kd_epoch_;
-        std::vector<Vec3> sample((size_t)K);
-        std::vector<uint32_t> rng_before((size_t)K + 1);
-        for (int i = 0; i < K; i++) { rng_before[i] = eng_.state(); sample[i] = genSample(); }
-        rng_before[K] = eng_.state();
+        const int32_t nearest = nearest_sphere(sample);
+        if (nearest == kNone || !T_.alive[nearest]) return;
+        const Vec3 c = steer(sample, nearest);
+        accept(c, clearance(c), nearest, refine, nullptr);
+    }
+    struct Lookahead {
+        std::vector<Vec3> sample;
+        std::vector<uint32_t> rng_before;       // generator state before sample i was drawn (entry K: after the last)
+        void draw_all(SafeRegionRrtStar &f, int K)
+        {
+            sample.resize((size_t)K);
+            rng_before.resize((size_t)K + 1);
+            for (int i = 0; i < K; i++) { rng_before[(size_t)i] = f.rng_.state(); sample[(size_t)i] = f.draw(); }
+            rng_before[(size_t)K] = f.rng_.state();
+        }
+    };
+    // the prepared neighbourhood of an accepted-looking candidate: from the batch's candidate ids when they were complete
+    kdres *neighbourhood_from(const Vec3 &centre, double radius, const uint32_t *ids, int32_t count, int32_t n0)
+    {
+        const float r = (float)radius;
+        if (centre.z < box_z_.first || r < safety_margin_) return nullptr;          // accept() will reject it before looking
+        const float cposf[3] = { (float)centre.x, (float)centre.y, (float)centre.z };
+        return count >= 0 ? kdx_range_from_candidates(kd_, cposf, r * 2.0f, ids, count, n0) : kd_nearest_rangef(kd_, cposf, r * 2.0f);
+    }
+
+    // Speculative batch with ONE launch: kdx_expand_batch answers nearest sphere -> steer -> clearance -> neighbourhood candidates
+    // of every sample in a single kernel against the tree as it is now.  The host replays the samples in order; a sample whose
+    // nearest sphere turns out to be one added earlier in the batch stops the replay, and the REST of the batch is re-evaluated
+    // against the tree as it is then (one launch again; the conflicting sample is first in line and cannot conflict).  If the
+    // sampling distribution or the kd tree itself changed (a route was found / improved, a sweep rebuilt the tree) the remaining
+    // samples are dropped and the generator is rewound, so the sequence of samples is exactly the sequential one.  Returns the
+    // number of samples consumed.
+    int grow_fused(int K, bool refine)
+    {
+        const uint64_t sampler0 = sampler_version_, kd0 = kd_version_;
+        Lookahead la;
+        la.draw_all(*this, K);
         const int cap = 256;
-        std::vector<double> sflat((size_t)3 * K);
+        std::vector<double> flat((size_t)3 * K);
         std::vector<pct_expand_result> res((size_t)K);
         std::vector<uint32_t> ids((size_t)K * cap);
         int pos = 0;
         while (pos < K) {
-            const int32_t n0 = kdx_size(kdTree_);
+            const int32_t n0 = kdx_size(kd_);
             const int m = K - pos;
-            for (int i = 0; i < m; i++) { sflat[3 * i] = sample[pos + i].x; sflat[3 * i + 1] = sample[pos + i].y; sflat[3 * i + 2] = sample[pos + i].z; }
-            if (kdx_expand_batch(kdTree_, map_.handle(), &map_.params(), sflat.data(), m, cap, res.data(), ids.data()) != 0) {
-                fused_ok_ = false;                                   // e.g. obstacle cloud without its cell index: staged path from here on
-                eng_.setState(rng_before[pos]);
-                return pos > 0 ? pos : growBatchStaged(K, refine);
+            for (int i = 0; i < m; i++) { const Vec3 &s = la.sample[(size_t)(pos + i)]; flat[3 * (size_t)i] = s.x; flat[3 * (size_t)i + 1] = s.y; flat[3 * (size_t)i + 2] = s.z; }
+            if (kdx_expand_batch(kd_, map_.handle(), &map_.params(), flat.data(), m, cap, res.data(), ids.data()) != 0) {
+                fused_ = false;                                       // e.g. obstacle cloud without its cell index: staged path from here on
+                rng_.setState(la.rng_before[(size_t)pos]);
+                return pos > 0 ? pos : grow_staged(K, refine);
             }
-            n_launch_++;
+            n_fused_launches_++;
             int i = pos;
             for (; i < K; i++) {
-                if (sample_epoch_ != epoch0 || kd_epoch_ != kd_epoch0) {   // what sample i would be, or the tree it would see, changed
-                    eng_.setState(rng_before[i]);
-                    return i;
-                }
+                if (sampler_version_ != sampler0 || kd_version_ != kd0) { rng_.setState(la.rng_before[(size_t)i]); return i; }
                 const pct_expand_result &e = res[(size_t)(i - pos)];
-                const int32_t n_now = kdx_size(kdTree_);
-                int32_t best = e.near_idx;
-                if (best < 0) {                                       // the tree was empty at the snapshot
-                    if (n_now == 0) continue;                         // findNearstVertex finds nothing: the sample is skipped
+                const int32_t n_now = kdx_size(kd_);
+                const int32_t slot = e.near_idx;
+                if (slot < 0) {                                       // the tree was empty at the snapshot
+                    if (n_now == 0) continue;                         // nothing to be nearest to: the sample is skipped
                     break;
                 }
-                const float qf[3] = { (float)sample[i].x, (float)sample[i].y, (float)sample[i].z };
-                double best_d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, best))->coord, qf);
-                bool conflict = false;
-                for (int32_t j = n0; j < n_now && !conflict; j++)     // a node added during this batch is strictly closer?
-                    conflict = kdDist2(((NodePtr)kdx_node_data(kdTree_, j))->coord, qf) < best_d2;
-                if (conflict) break;
-                NodePtr nearest = (NodePtr)kdx_node_data(kdTree_, best);
-                if (!nearest->valid) continue;                        // as the reference: skip the sample
-                n_inflate_++;
-                if (i > pos) n_spec_hit_++;
-                const Vec3 center(e.center[0], e.center[1], e.center[2]);
-                NodePtr fresh = new CorridorNode(center, (float)e.radius, (float)kInf, (float)getDis(center, end_pt));
-                kdres *pre = nullptr;
-                if (!(fresh->coord.z < z_l || fresh->radius < safety_margin_)) {
-                    const float cposf[3] = { (float)center.x, (float)center.y, (float)center.z };
-                    const float r = fresh->radius * 2.0f;
-                    pre = e.count >= 0 ? kdx_range_from_candidates(kdTree_, cposf, r, &ids[(size_t)(i - pos) * cap], e.count, n0)
-                                       : kd_nearest_rangef(kdTree_, cposf, r);
-                }
-                finishGrow(fresh, nearest, refine, pre);
+                const float qf[3] = { (float)la.sample[(size_t)i].x, (float)la.sample[(size_t)i].y, (float)la.sample[(size_t)i].z };
+                const int32_t nearest = untag(kdx_node_data(kd_, slot));
+                const double d2 = kd_d2(T_.centre[nearest], qf);
+                bool overtaken = false;                               // a sphere added during this batch is strictly closer?
+                for (int32_t j = n0; j < n_now && !overtaken; j++) overtaken = kd_d2(T_.centre[untag(kdx_node_data(kd_, j))], qf) < d2;
+                if (overtaken) break;
+                if (!T_.alive[nearest]) continue;                     // as the reference: skip the sample
+                n_clearance_++;
+                if (i > pos) n_replayed_++;
+                const Vec3 c(e.center[0], e.center[1], e.center[2]);
+                accept(c, e.radius, nearest, refine, neighbourhood_from(c, e.radius, &ids[(size_t)(i - pos) * cap], e.count, n0));
             }
             if (i == K) break;
-            if (i == pos) { growWithSample(sample[i], refine); i++; }   // cannot happen (nothing is younger than the snapshot); never loop
-            else n_spec_miss_++;
+            if (i == pos) { grow_one(la.sample[(size_t)i], refine); i++; }      // cannot happen (nothing is younger than the snapshot); never loop
+            else n_restarts_++;
             pos = i;
         }
         return K;
     }
-
-    int growBatchStaged(int K, bool refine)
+    // the same speculation with three batched launches (nearest, clearance, neighbourhood) and a one-by-one fallback per sample
+    int grow_staged(int K, bool refine)
     {
-        const uint64_t epoch0 = sample_epoch_, kd_epoch0 = kd_epoch_;
-        const int32_t n0 = kdx_size(kdTree_);
-        std::vector<Vec3> sample((size_t)K);
-        std::vector<uint32_t> rng_before((size_t)K + 1);
+        const uint64_t sampler0 = sampler_version_, kd0 = kd_version_;
+        const int32_t n0 = kdx_size(kd_);
+        Lookahead la;
+        la.draw_all(*this, K);
         std::vector<float> posf((size_t)3 * K);
+        for (int i = 0; i < K; i++) { const Vec3 &s = la.sample[(size_t)i]; posf[3 * (size_t)i] = (float)s.x; posf[3 * (size_t)i + 1] = (float)s.y; posf[3 * (size_t)i + 2] = (float)s.z; }
+        std::vector<int32_t> slot((size_t)K, -1);
+        kdx_nearestf_batch(kd_, posf.data(), K, slot.data());
+        std::vector<Vec3> centre((size_t)K);
+        std::vector<double> flat((size_t)3 * K), radius((size_t)K, 0.0);
         for (int i = 0; i < K; i++) {
-            rng_before[i] = eng_.state();
-            sample[i] = genSample();
-            posf[3 * i] = (float)sample[i].x; posf[3 * i + 1] = (float)sample[i].y; posf[3 * i + 2] = (float)sample[i].z;
+            centre[(size_t)i] = slot[(size_t)i] >= 0 ? steer(la.sample[(size_t)i], untag(kdx_node_data(kd_, slot[(size_t)i]))) : la.sample[(size_t)i];
+            flat[3 * (size_t)i] = centre[(size_t)i].x; flat[3 * (size_t)i + 1] = centre[(size_t)i].y; flat[3 * (size_t)i + 2] = centre[(size_t)i].z;
         }
-        rng_before[K] = eng_.state();
-        // stage A: nearest tree node of every sample
-        std::vector<int32_t> near_idx((size_t)K, -1);
-        kdx_nearestf_batch(kdTree_, posf.data(), K, near_idx.data());
-        // stage B: steer + inflate the candidate centres
-        std::vector<Vec3> center((size_t)K);
-        std::vector<double> cflat((size_t)3 * K), radius((size_t)K, 0.0);
-        for (int i = 0; i < K; i++) {
-            NodePtr nearest = near_idx[i] >= 0 ? (NodePtr)kdx_node_data(kdTree_, near_idx[i]) : nullptr;
-            center[i] = nearest ? steer(sample[i], nearest) : sample[i];
-            cflat[3 * i] = center[i].x; cflat[3 * i + 1] = center[i].y; cflat[3 * i + 2] = center[i].z;
-        }
-        map_.checkRadiusBatch(cflat.data(), K, radius.data());
-        // stage C: neighbourhood candidates for treeRewire (range = 2 * float radius, centre narrowed to float)
+        map_.checkRadiusBatch(flat.data(), K, radius.data());
         std::vector<float> cposf((size_t)3 * K), range((size_t)K);
         for (int i = 0; i < K; i++) {
-            cposf[3 * i] = (float)center[i].x; cposf[3 * i + 1] = (float)center[i].y; cposf[3 * i + 2] = (float)center[i].z;
-            range[i] = std::max((float)radius[i], 0.0f) * 2.0f;
+            cposf[3 * (size_t)i] = (float)centre[(size_t)i].x; cposf[3 * (size_t)i + 1] = (float)centre[(size_t)i].y; cposf[3 * (size_t)i + 2] = (float)centre[(size_t)i].z;
+            range[(size_t)i] = std::max((float)radius[(size_t)i], 0.0f) * 2.0f;
         }
         const int cap = 256;
         std::vector<uint32_t> ids((size_t)K * cap);
         std::vector<int32_t> counts((size_t)K, -1);
-        kdx_range_candidates_batch(kdTree_, cposf.data(), range.data(), K, ids.data(), cap, counts.data());
-
-        // replay, in order
+        kdx_range_candidates_batch(kd_, cposf.data(), range.data(), K, ids.data(), cap, counts.data());
         for (int i = 0; i < K; i++) {
-            if (sample_epoch_ != epoch0 || kd_epoch_ != kd_epoch0) {      // what sample i would be, or the tree it would see, changed
-                eng_.setState(rng_before[i]);
-                return i;
-            }
-            // exact nearest = snapshot winner unless a node added during this batch is strictly closer
-            int32_t best = near_idx[i];
-            if (best < 0) { growWithSample(sample[i], refine); n_spec_miss_++; continue; }
-            const float *qf = &posf[3 * i];
-            double best_d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, best))->coord, qf);
-            const int32_t n_now = kdx_size(kdTree_);
+            if (sampler_version_ != sampler0 || kd_version_ != kd0) { rng_.setState(la.rng_before[(size_t)i]); return i; }
+            if (slot[(size_t)i] < 0) { grow_one(la.sample[(size_t)i], refine); n_restarts_++; continue; }
+            // the snapshot's winner stands unless a sphere added during this batch is strictly closer
+            const float *qf = &posf[3 * (size_t)i];
+            int32_t best = slot[(size_t)i];
+            double d2 = kd_d2(T_.centre[untag(kdx_node_data(kd_, best))], qf);
+            const int32_t n_now = kdx_size(kd_);
             for (int32_t j = n0; j < n_now; j++) {
-                const double d2 = kdDist2(((NodePtr)kdx_node_data(kdTree_, j))->coord, qf);
-                if (d2 < best_d2) { best_d2 = d2; best = j; }
+                const double dj = kd_d2(T_.centre[untag(kdx_node_data(kd_, j))], qf);
+                if (dj < d2) { d2 = dj; best = j; }
             }
-            if (best != near_idx[i]) { growWithSample(sample[i], refine); n_spec_miss_++; continue; }   // centre differs: one-by-one
-            NodePtr nearest = (NodePtr)kdx_node_data(kdTree_, best);
-            if (!nearest->valid) continue;                                                               // as the reference: skip the sample
-            n_inflate_++;
-            n_spec_hit_++;
-            NodePtr fresh = new CorridorNode(center[i], (float)radius[i], (float)kInf, (float)getDis(center[i], end_pt));
-            kdres *pre = nullptr;
-            if (!(fresh->coord.z < z_l || fresh->radius < safety_margin_)) {
-                const float r = fresh->radius * 2.0f;
-                pre = counts[i] >= 0 ? kdx_range_from_candidates(kdTree_, &cposf[3 * i], r, &ids[(size_t)i * cap], counts[i], n0)
-                                     : kd_nearest_rangef(kdTree_, &cposf[3 * i], r);
-            }
-            finishGrow(fresh, nearest, refine, pre);
+            if (best != slot[(size_t)i]) { grow_one(la.sample[(size_t)i], refine); n_restarts_++; continue; }    // the centre would differ
+            const int32_t nearest = untag(kdx_node_data(kd_, best));
+            if (!T_.alive[nearest]) continue;
+            n_clearance_++;
+            n_replayed_++;
+            accept(centre[(size_t)i], radius[(size_t)i], nearest, refine,
+                   neighbourhood_from(centre[(size_t)i], radius[(size_t)i], &ids[(size_t)i * cap], counts[(size_t)i], n0));
         }
         return K;
     }
 
-    Vec3 steer(const Vec3 &pt_sample, NodePtr nearest) const             // the first half of genNewNode (:387-404)
-    {
-        const double dis = getDis(nearest->coord, pt_sample);
-        if (dis > nearest->radius) {
-            const double steer_dis = nearest->radius / dis;
-            return Vec3(nearest->coord.x + (pt_sample.x - nearest->coord.x) * steer_dis,
-                        nearest->coord.y + (pt_sample.y - nearest->coord.y) * steer_dis,
-                        nearest->coord.z + (pt_sample.z - nearest->coord.z) * steer_dis);
-        }
-        return pt_sample;
-    }
-
-    void clearBranchW(NodePtr node)                                                             // :135-149
-    {
-        for (auto n : node->nxtNode_ptr) {
-            if (n->best) continue;
-            if (n->valid) invalidSet.push_back(n);
-            n->valid = false;
-            clearBranchW(n);
-        }
-    }
-    void clearBranchS(NodePtr node)                                                             // :151-159
-    {
-        for (auto n : node->nxtNode_ptr) {
-            if (n->valid) invalidSet.push_back(n);
-            n->valid = false;
-            clearBranchS(n);
-        }
-    }
-    void treePrune(NodePtr p)                                                                   // :161-169
-    {
-        if (p->g + p->f > best_distance) {
-            p->valid = false;
-            invalidSet.push_back(p);
-            clearBranchS(p);
-        }
-    }
-    void removeInvalid()                                                                        // :170-231
-    {
-        std::vector<NodePtr> keep, ends;
-        kd_epoch_++;                  // node numbers of the kd tree change
-        kd_clear(kdTree_);
-        for (auto n : NodeList)
-            if (n->valid) {
-                insertKd(n);
-                keep.push_back(n);
-                if (checkEnd(n)) ends.push_back(n);
-            }
-        NodeList = keep;
-        EndList = ends;
-        for (auto n : invalidSet)
-            if (n->preNode_ptr != nullptr) {
-                n->change = true;
-                const std::vector<NodePtr> child = n->preNode_ptr->nxtNode_ptr;
-                n->preNode_ptr->nxtNode_ptr.clear();
-                for (auto c : child) if (!c->change) n->preNode_ptr->nxtNode_ptr.push_back(c);
-            }
-        std::vector<NodePtr> deleteList;
-        for (auto n : invalidSet) {
-            for (auto c : n->nxtNode_ptr) if (c->valid) c->preNode_ptr = nullptr;
-            deleteList.push_back(n);
-        }
-        invalidSet.clear();
-        for (auto n : deleteList) delete n;
-    }
-    void treeRewire(NodePtr newPtr, NodePtr nearestPtr, kdres *presults = nullptr)              // :457-567
-    {
-        if (!presults) {
-            const float range = newPtr->radius * 2.0f;
-            float pos[3] = { (float)newPtr->coord.x, (float)newPtr->coord.y, (float)newPtr->coord.z };
-            presults = must(kd_nearest_rangef(kdTree_, pos, range), "kd_nearest_rangef");
-        }
-        std::vector<NodePtr> nearPtrList;
-        bool isInvalid = false;
-        while (!kd_res_end(presults)) {
-            NodePtr nearPtr = (NodePtr)kd_res_item_data(presults);
-            const double dis = getDis(nearPtr->coord, newPtr->coord);
-            const int res = checkNodeRelation(dis, nearPtr, newPtr);
-            nearPtr->rel_id = res;
-            nearPtr->rel_dis = (float)dis;
-            nearPtrList.push_back(nearPtr);
-            if (res == 1) { newPtr->valid = false; isInvalid = true; break; }
-            kd_res_next(presults);
-        }
-        kd_res_free(presults);
-        if (isInvalid) {
-            for (auto n : nearPtrList) { n->rel_id = -2; n->rel_dis = -1.0f; }
-            return;
-        }
-        double min_cost = nearestPtr->g + getDis(nearestPtr->coord, newPtr->coord);
-        newPtr->preNode_ptr = nearestPtr;
-        newPtr->g = (float)min_cost;
-        nearestPtr->nxtNode_ptr.push_back(newPtr);
-        NodePtr lstParentPtr = nearestPtr;
-        std::vector<NodePtr> nearVertex;
-        for (auto nearPtr : nearPtrList) {
-            const int res = nearPtr->rel_id;
-            const double dis = nearPtr->rel_dis;
-            const double cost = nearPtr->g + dis;
-            if (res == -1) {
-                if (cost < min_cost) {
-                    min_cost = cost;
-                    newPtr->preNode_ptr = nearPtr;
-                    newPtr->g = (float)min_cost;
-                    lstParentPtr->nxtNode_ptr.pop_back();
-                    lstParentPtr = nearPtr;
-                    lstParentPtr->nxtNode_ptr.push_back(newPtr);
-                }
-                nearVertex.push_back(nearPtr);
-            }
-            nearPtr->rel_id = -2;
-            nearPtr->rel_dis = -1.0f;
-        }
-        for (auto nearPtr : nearVertex) {
-            if (!nearPtr->valid) continue;
-            const double dis = getDis(nearPtr->coord, newPtr->coord);
-            const double cost = dis + newPtr->g;
-            if (cost < nearPtr->g) {
-                if (isSuccessor(nearPtr, newPtr->preNode_ptr)) continue;
-                if (nearPtr->preNode_ptr == nullptr) {
-                    nearPtr->preNode_ptr = newPtr;
-                    nearPtr->g = (float)cost;
-                } else {
-                    NodePtr lstNearParent = nearPtr->preNode_ptr;
-                    nearPtr->preNode_ptr = newPtr;
-                    nearPtr->g = (float)cost;
-                    nearPtr->change = true;
-                    const std::vector<NodePtr> child = lstNearParent->nxtNode_ptr;
-                    lstNearParent->nxtNode_ptr.clear();
-                    for (auto c : child) if (!c->change) lstNearParent->nxtNode_ptr.push_back(c);
-                    nearPtr->change = false;
-                }
-                newPtr->nxtNode_ptr.push_back(nearPtr);
-            }
-        }
-    }
-    void tracePath()                                                                            // :575-643
-    {
-        std::vector<NodePtr> feasibleEndList;
-        for (auto e : EndList)
-            if (checkValidEnd(e) && checkEnd(e) && e->valid) feasibleEndList.push_back(e);
-        if (feasibleEndList.empty()) {
-            path_exist_status = false;
-            best_distance = kInf;
-            inform_status = false;
-            EndList.clear();
-            Path = { Vec3(1, 0, 0), Vec3(0, 1, 0), Vec3(0, 0, 1) };          // MatrixXd::Identity(3,3)
-            Radius = { 0.0, 0.0, 0.0 };
-            return;
-        }
-        EndList = feasibleEndList;
-        best_end_ptr = feasibleEndList[0];
-        double best_cost = kInf;
-        for (auto n : feasibleEndList) {
-            const double cost = n->g + getDis(n->coord, end_pt) + getDis(root_node->coord, commit_root);
-            if (cost < best_cost) { best_end_ptr = n; best_cost = cost; best_distance = best_cost; }
-        }
-        PathList.clear();
-        for (NodePtr p = best_end_ptr; p != nullptr; p = p->preNode_ptr) PathList.push_back(p);
-        const size_t k = PathList.size();
-        Path.assign(k, Vec3());
-        Radius.assign(k, 0.0);
-        for (size_t i = 0; i < k; i++) { Path[k - 1 - i] = PathList[i]->coord; Radius[k - 1 - i] = PathList[i]->radius; }
-        path_exist_status = true;
-    }
-    // One batch per pass (corridor_finder.cpp:938-1021).  The reference asks, per failed node, one kd_nearest_rangef and then one
-    // radiusSearch per valid neighbour, each a launch + a host round trip here.  Neither the node tree nor the obstacle cloud changes
-    // inside the loop (nodes are only marked invalid; removeInvalid runs after it), and radiusSearch is a pure function of the
-    // neighbour's centre, so: ONE launch finds the neighbourhood candidates of every failed node, ONE launch inflates every node
-    // that could be re-checked, and the reference's per-node logic then runs on the host in its own order with those answers.
-    void treeRepair(std::vector<std::pair<Vec3, double>> &node_list)                            // :938-1021
-    {
-        const int K = (int)node_list.size();
-        if (K == 0) { removeInvalid(); return; }
-        const int32_t n0 = kdx_size(kdTree_);
-        const int cap = 256;
-        std::vector<float> posf((size_t)3 * K), range((size_t)K);
-        for (int i = 0; i < K; i++) {
-            const Vec3 &c = node_list[(size_t)i].first;
-            posf[3 * (size_t)i] = (float)c.x; posf[3 * (size_t)i + 1] = (float)c.y; posf[3 * (size_t)i + 2] = (float)c.z;
-            range[(size_t)i] = (float)node_list[(size_t)i].second * 2.0f;
-        }
-        std::vector<kdres *> sets((size_t)K, nullptr);
-        struct Free { std::vector<kdres *> &v; ~Free() { for (auto r : v) if (r) kd_res_free(r); } } guard{ sets };
-        {
-            std::vector<uint32_t> ids((size_t)K * cap);
-            std::vector<int32_t> counts((size_t)K);
-            for (int b0 = 0; b0 < K; b0 += 1024) {             // kdx batches hold at most 1024 queries
-                const int m = std::min(1024, K - b0);
-                const bool ok = kdx_range_candidates_batch(kdTree_, &posf[3 * (size_t)b0], &range[(size_t)b0], m, &ids[(size_t)b0 * cap], cap, &counts[(size_t)b0]) == 0;
-                n_repair_batches_++;
-                for (int i = b0; i < b0 + m; i++)
-                    sets[(size_t)i] = must(ok && counts[(size_t)i] >= 0 ? kdx_range_from_candidates(kdTree_, &posf[3 * (size_t)i], range[(size_t)i], &ids[(size_t)i * cap], counts[(size_t)i], n0)
-                                                                        : kd_nearest_rangef(kdTree_, &posf[3 * (size_t)i], range[(size_t)i]), "kd_nearest_rangef");
-            }
-        }
-        // every node the loop below may re-check: in some failed node's neighbourhood, still valid, not the root nor its child
-        std::vector<NodePtr> cand;
-        for (int i = 0; i < K; i++) {
-            for (kd_res_rewind(sets[(size_t)i]); !kd_res_end(sets[(size_t)i]); kd_res_next(sets[(size_t)i])) {
-                NodePtr ptr = (NodePtr)kd_res_item_data(sets[(size_t)i]);
-                if (!ptr->valid || ptr->preNode_ptr == root_node || ptr == root_node || ptr->rel_id == -3) continue;
-                ptr->rel_id = -3;                              // scratch mark (restored below): listed once
-                cand.push_back(ptr);
-            }
-            kd_res_rewind(sets[(size_t)i]);
-        }
-        std::vector<double> coords(3 * cand.size()), radii(cand.size());
-        for (size_t k = 0; k < cand.size(); k++) {
-            cand[k]->rel_id = -2;
-            coords[3 * k] = cand[k]->coord.x; coords[3 * k + 1] = cand[k]->coord.y; coords[3 * k + 2] = cand[k]->coord.z;
-        }
-        if (!cand.empty()) { map_.checkRadiusBatch(coords.data(), (int64_t)cand.size(), radii.data()); n_repair_batches_++; }
-        std::unordered_map<NodePtr, double> fresh;
-        fresh.reserve(cand.size() * 2);
-        for (size_t k = 0; k < cand.size(); k++) fresh.emplace(cand[k], radii[k]);
-
-        for (int i = 0; i < K; i++) {
-            kdres *presults = sets[(size_t)i];
-            while (!kd_res_end(presults)) {
-                NodePtr ptr = (NodePtr)kd_res_item_data(presults);
-                kd_res_next(presults);
-                if (!ptr->valid) continue;
-                NodePtr pre_ptr = ptr->preNode_ptr;
-                if (pre_ptr == root_node || ptr == root_node) continue;
-                const auto it = fresh.find(ptr);
-                const double update_radius = it != fresh.end() ? it->second : radiusSearch(ptr->coord);
-                if (it != fresh.end()) n_inflate_++;           // counted where the reference calls radiusSearch
-                const int ret = checkNodeUpdate(update_radius, ptr->radius);
-                ptr->radius = (float)update_radius;
-                syncNodeAux(ptr);
-                if (ret == -1) {
-                    if (ptr->valid) { ptr->valid = false; invalidSet.push_back(ptr); clearBranchS(ptr); }
-                    continue;
-                }
-                if (pre_ptr == nullptr) continue;      // the reference dereferences a NULL parent here; a parentless non-root node has nothing to re-check
-                const double dis = getDis(pre_ptr->coord, ptr->coord);
-                if (checkNodeRelation(dis, pre_ptr, ptr) != -1 && pre_ptr->valid) {
-                    pre_ptr->valid = false;
-                    invalidSet.push_back(pre_ptr);
-                    clearBranchS(pre_ptr);
-                    continue;
-                }
-                const std::vector<NodePtr> childList = ptr->nxtNode_ptr;
-                for (auto child : childList)
-                    if (checkNodeRelation(getDis(ptr->coord, child->coord), ptr, child) != -1 && child->valid) {
-                        child->valid = false;
-                        invalidSet.push_back(child);
-                        clearBranchS(child);
-                    }
-            }
-        }
-        removeInvalid();
-    }
-    void treeDestruct()                                                                         // :645-654
-    {
-        if (kdTree_) { kd_free(kdTree_); kdTree_ = nullptr; }
-        for (auto n : NodeList) delete n;
-        NodeList.clear();
-        for (auto n : discarded_) delete n;      // the reference leaks rejected nodes; they are reclaimed here
-        discarded_.clear();
-    }
-
     ObstacleMap map_;
-    kdtree *kdTree_ = nullptr;
-    std::vector<NodePtr> NodeList, EndList, PathList, invalidSet, discarded_;
-    NodePtr best_end_ptr = nullptr, root_node = nullptr, best_end_owned_ = nullptr, root_owned_ = nullptr;
-    Vec3 start_pt, end_pt, commit_root, translation_inf, rot_c0, rot_c1, rot_c2;
-    int cach_size = 10;                      // corridor_finder.cpp:8
-    int max_samples = 30000;
-    double x_l = 0, x_h = 0, y_l = 0, y_h = 0, z_l = 0, z_h = 0, inlier_ratio = 0, goal_ratio = 0;
-    double x_in_lo = 0, x_in_hi = 0, y_in_lo = 0, y_in_hi = 0, z_lo = 0, z_hi = 0;
+    kdtree *kd_ = nullptr;
+    detail::SphereArena T_;
+    std::vector<int32_t> order_;             // live spheres in insertion order (the reference's NodeList): kd rebuilds follow it
+    std::vector<int32_t> goal_ids_;          // spheres that touch the goal (EndList), in discovery order: ties go to the first
+    std::vector<int32_t> route_;             // the chosen route, goal end first (PathList)
+    std::vector<int32_t> doomed_, walk_;
+    struct NearRec { int32_t id; int rel; float d; };
+    std::vector<NearRec> near_;
+    int condemn_events_ = 0;
+    static constexpr int sweep_after_ = 10;  // cach_size, corridor_finder.cpp:8
+    int32_t root_ = kNone, best_goal_ = kNone;
+    Vec3 start_, goal_, committed_, ell_centre_, ell_u_, ell_v_, ell_w_;
+    std::pair<double, double> box_x_{ 0, 0 }, box_y_{ 0, 0 }, box_z_{ 0, 0 }, near_x_{ 0, 0 }, near_y_{ 0, 0 }, sample_z_{ 0, 0 };
+    int max_samples_ = 30000;
+    double near_share_ = 0, goal_share_ = 0;
     double safety_margin_ = 0, max_radius_ = 0, search_margin_ = 0, sample_range_ = 0;
-    double min_distance = 0, best_distance = kInf, elli_l = 0, elli_s = 0;
-    bool inform_status = false, path_exist_status = true, global_navi_status = false;
-    std::vector<Vec3> Path;
-    std::vector<double> Radius;
-    MinStdRand0 eng_;
-    uint64_t n_inflate_ = 0, n_spec_hit_ = 0, n_spec_miss_ = 0, sample_epoch_ = 0, kd_epoch_ = 0, n_launch_ = 0, n_repair_batches_ = 0;
-    bool fused_ok_ = true;          // one-launch expansion batches (kdx_expand_batch); false = the three-stage form
-    int spec_k_ = 64;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
+    double direct_ = 0, best_cost_ = kInf, ell_long_ = 0, ell_short_ = 0;
+    bool informed_ = false, path_exists_ = true, reached_commit_ = false;
+    std::vector<Vec3> path_centres_;
+    std::vector<double> path_radii_;
+    MinStdRand0 rng_;
+    uint64_t n_clearance_ = 0, n_replayed_ = 0, n_restarts_ = 0, sampler_version_ = 0, kd_version_ = 0, n_fused_launches_ = 0, n_repair_trips_ = 0;
+    bool fused_ = true;             // one-launch expansion batches (kdx_expand_batch); false = the three-stage form
+    int ahead_ = 64;                // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop
 };
 
 }  // namespace pct

@@ -100,7 +100,7 @@ int pct_corridor_status(pct_corridor *c, int *path_exists, int *global_navi, int
     return guarded([&] {
         if (path_exists) *path_exists = c->impl->getPathExistStatus() ? 1 : 0;
         if (global_navi) *global_navi = c->impl->getGlobalNaviStatus() ? 1 : 0;
-        if (n_nodes) *n_nodes = (int64_t)c->impl->getTree().size();
+        if (n_nodes) *n_nodes = (int64_t)c->impl->treeSize();
         if (inflation_queries) *inflation_queries = c->impl->inflationQueries();
     });
 }

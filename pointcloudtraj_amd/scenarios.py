@@ -50,6 +50,37 @@ def run_scenario(finder, cloud1, cloud2=None, expand=1500, refine=400):
     return out
 
 
+def run_commit_scenario(finder, cloud1, expand=800, refine=300, commits=3):
+    """planIncrementalTraj's flow (sim_planning_demo.cpp:393-460): after the first corridor the drone commits to a point on it,
+    the finder moves its root there (resetRoot), refines, and re-evaluates against the next frame -- `commits` times.  The commit
+    target is the centre of the corridor's third sphere (inside the root-side spheres, as the committed trajectory end is)."""
+    p = PARAMS
+    out = []
+    finder.setParam(p["safety_margin"], p["search_margin"], p["max_radius"], p["sensing_range"])
+    finder.setInput(cloud1)
+    finder.reset()
+    finder.setPt(START, GOAL, *BOUNDS, p["sensing_range"], p["max_samples"], p["sample_portion"], p["goal_portion"])
+    finder.SafeRegionExpansion(expand)
+    finder.SafeRegionRefine(refine)
+    out.append((*finder.getPath(), finder.status()))
+    cloud = cloud1
+    for k in range(commits):
+        path, _ = finder.getPath()
+        if not finder.status()["path_exists"] or len(path) < 4:
+            break
+        target = tuple(float(v) for v in path[2])
+        finder.setStartPt(target, GOAL)
+        finder.resetRoot(target)
+        out.append((*finder.getPath(), finder.status()))       # the path is only re-traced by the next phase; the status moves now
+        finder.SafeRegionRefine(refine // 2)
+        out.append((*finder.getPath(), finder.status()))
+        cloud = perturbed_cloud(cloud, finder.getPath()[0])
+        finder.setInput(cloud)
+        finder.SafeRegionEvaluate()
+        out.append((*finder.getPath(), finder.status()))
+    return out
+
+
 def timed_scenario(finder, cloud1, expand=1500, refine=400):
     """run_scenario with wall-clock milliseconds per planner phase (bench.py / scripts/probe_corridor.py)"""
     import time

@@ -3,7 +3,7 @@ finder against the oracle (two independent implementations, no shared code) for 
 import numpy as np
 import pytest
 
-from pointcloudtraj_amd.scenarios import GOAL, START, run_scenario, sensed_cloud
+from pointcloudtraj_amd.scenarios import GOAL, START, run_commit_scenario, run_scenario, sensed_cloud
 
 
 def check_corridor(path, radius, cloud, safety=0.6):
@@ -72,3 +72,37 @@ def test_gpu_corridor_matches_oracle(oracle, speculation, fused):
             # the drastically different second frame invalidates corridor nodes: SafeRegionEvaluate hands them to treeRepair, which now
             # makes two GPU round trips per pass whatever the number of neighbours (it used to make two per neighbour)
             assert 0 < finder.repairBatches() <= 8, finder.repairBatches()
+
+
+def test_oracle_commit_scenario_moves_the_root(oracle):
+    """the commit scenario really exercises resetRoot: the root moves, nodes behind it are cut, and the run is deterministic"""
+    cloud1 = sensed_cloud(12.0)
+    phases = run_commit_scenario(oracle.PortCorridor(), cloud1)
+    assert len(phases) >= 4, "at least one commit must have happened"
+    assert phases[0][2]["path_exists"]
+    first_path = phases[0][0]
+    moved = [ph for ph in phases[2:] if ph[2]["path_exists"] and not np.array_equal(ph[0][0], first_path[0])]
+    assert moved, "after a commit the corridor must start at the new root"
+    again = run_commit_scenario(oracle.PortCorridor(), cloud1)
+    for (pa, ra, sa), (pb, rb, sb) in zip(phases, again):
+        assert np.array_equal(pa, pb) and np.array_equal(ra, rb) and sa == sb
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("speculation", [1, 64])
+def test_gpu_commit_scenario_matches_oracle(oracle, speculation):
+    """resetRoot / setStartPt / Refine / Evaluate in the planner's incremental order: corridor, radii, node and query counts equal the
+    independent CPU restatement's after every phase"""
+    from pointcloudtraj_amd import corridor, engine
+    engine.init(0)
+    cloud1 = sensed_cloud(12.0)
+    want = run_commit_scenario(oracle.PortCorridor(), cloud1)
+    finder = corridor.SafeRegionRrtStar(80000)
+    finder.setSpeculation(speculation)
+    got = run_commit_scenario(finder, cloud1)
+    assert len(want) == len(got) >= 4
+    for k, ((pw, rw, sw), (pg, rg, sg)) in enumerate(zip(want, got)):
+        assert sw["path_exists"] == sg["path_exists"] and sw["global_navi"] == sg["global_navi"] and sw["nodes"] == sg["nodes"], f"phase {k}: {sw} vs {sg}"
+        assert np.array_equal(pw, pg), f"phase {k}: corridor centres differ"
+        assert np.array_equal(rw, rg), f"phase {k}: corridor radii differ"
+        assert sw["inflation_queries"] == sg["inflation_queries"], f"phase {k}"
