@@ -81,6 +81,7 @@ void dev_free(T *&p)
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 constexpr int kExpressMaxQ = 1024;        // queries per express (block-per-query) launch
+constexpr int64_t kMappedMaxQ = 65536;    // host-buffer batches up to this size travel through host-mapped memory, larger ones by DMA
 constexpr int64_t kSmallNNMax = 16384;    // clouds up to this size answer single queries with one-block kernels
 constexpr uint32_t kExpressIdsCap = 1u << 16;
 
@@ -115,6 +116,11 @@ struct pct_cloud {
     double *h_xin = nullptr, *d_xin = nullptr, *h_xr = nullptr, *d_xr = nullptr;
     uint32_t *h_xids = nullptr, *d_xids = nullptr;
     uint32_t *h_xseq = nullptr, *d_xseq = nullptr, *d_xcounter = nullptr;     // completion word of the express launches (kernels.hpp ExpressSignal)
+    // host-buffer batches of up to kMappedMaxQ queries: queries read from, results exported to, host-mapped memory (no DMA copies)
+    float *h_mq = nullptr, *d_mq = nullptr;
+    uint32_t *h_mi = nullptr, *d_mi = nullptr;
+    double *h_md = nullptr, *d_md = nullptr;
+    int64_t mcap = 0;
     uint32_t xseq = 0;
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
     double *h_aux = nullptr, *d_aux = nullptr;
@@ -257,6 +263,29 @@ int express_wait(pct_cloud *c)
     }
     HIPCHK(hipStreamSynchronize(g_stream));
     return PCT_OK;
+}
+
+// host-mapped query / result buffers of the mid-size host-buffer batches (grow-only, power of two)
+int ensure_mapped_io(pct_cloud *c, int64_t Q)
+{
+    if (Q <= c->mcap) return PCT_OK;
+    int64_t cap = 4096;
+    while (cap < Q) cap <<= 1;
+    if (c->h_mq) (void)hipHostFree(c->h_mq);
+    if (c->h_mi) (void)hipHostFree(c->h_mi);
+    if (c->h_md) (void)hipHostFree(c->h_md);
+    c->h_mq = nullptr; c->h_mi = nullptr; c->h_md = nullptr; c->mcap = 0;
+    PCTCHK(mapped_alloc(&c->h_mq, &c->d_mq, (size_t)(4 * cap)));          // 3 floats per query + a radius
+    PCTCHK(mapped_alloc(&c->h_mi, &c->d_mi, (size_t)cap));
+    PCTCHK(mapped_alloc(&c->h_md, &c->d_md, (size_t)cap));
+    c->mcap = cap;
+    return PCT_OK;
+}
+
+bool mapped_io_on()
+{
+    static const bool on = [] { const char *e = std::getenv("PCT_MAPPED_IO"); return e ? std::atoi(e) != 0 : true; }();
+    return on && poll_results();
 }
 
 int require_init()
@@ -1108,6 +1137,9 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     if (c->h_xseq) (void)hipHostFree(c->h_xseq);
+    if (c->h_mq) (void)hipHostFree(c->h_mq);
+    if (c->h_mi) (void)hipHostFree(c->h_mi);
+    if (c->h_md) (void)hipHostFree(c->h_md);
     dev_free(c->d_xcounter);
     if (c->h_aux) (void)hipHostFree(c->h_aux);
     if (c->h_eout) (void)hipHostFree(c->h_eout);
@@ -1440,6 +1472,21 @@ int pct_nn_batch_algo(pct_cloud *c, int algo, const float *q, int64_t Q, uint32_
         return PCT_OK;
     }
     PCTCHK(pct_cloud_reserve_queries(c, Q));
+    if (Q <= kMappedMaxQ && mapped_io_on()) {
+        // queries imported from host-mapped memory by a kernel, results exported by a kernel, completion by polling:
+        // no DMA copy, no stream synchronise (C2's 4096-query batch: 0.63 -> 0.5x ms)
+        PCTCHK(ensure_mapped_io(c, Q));
+        std::memcpy(c->h_mq, q, sizeof(float) * 3 * (size_t)Q);
+        import_floats_kernel<<<ceil_div(3 * Q, 256), 256, 0, g_stream>>>(c->d_mq, (uint32_t)(3 * Q), c->d_q);
+        PCTCHK(nn_dev(c, algo, c->d_q, Q, c->d_idx, c->d_d2, g_stream));
+        export_results_kernel<<<ceil_div(Q, 256), 256, 0, g_stream>>>(c->d_idx, c->d_d2, (uint32_t)Q, c->d_mi, c->d_md, next_signal(c));
+        HIPCHK(hipGetLastError());
+        PCTCHK(express_wait(c));
+        std::memcpy(idx, c->h_mi, sizeof(uint32_t) * (size_t)Q);
+        std::memcpy(d2, c->h_md, sizeof(double) * (size_t)Q);
+        if (c->count == 0) return fail(PCT_ERR_EMPTY, "nearest-neighbour query against an empty cloud");
+        return PCT_OK;
+    }
     HIPCHK(hipMemcpyAsync(c->d_q, q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
     PCTCHK(nn_dev(c, algo, c->d_q, Q, c->d_idx, c->d_d2, g_stream));
     HIPCHK(hipMemcpyAsync(idx, c->d_idx, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost, g_stream));
@@ -1511,6 +1558,19 @@ int pct_radius_count_batch_algo(pct_cloud *c, int algo, const float *q, const fl
     if (!c || Q < 0 || (Q > 0 && (!q || !r || !count))) return fail(PCT_ERR_INVALID, "bad radius_count arguments");
     if (Q == 0) return PCT_OK;
     PCTCHK(pct_cloud_reserve_queries(c, Q));
+    if (Q <= kMappedMaxQ && mapped_io_on()) {          // as pct_nn_batch_algo: kernels move the arguments and the counts, the host polls
+        PCTCHK(ensure_mapped_io(c, Q));
+        std::memcpy(c->h_mq, q, sizeof(float) * 3 * (size_t)Q);
+        std::memcpy(c->h_mq + 3 * Q, r, sizeof(float) * (size_t)Q);
+        import_floats_kernel<<<ceil_div(3 * Q, 256), 256, 0, g_stream>>>(c->d_mq, (uint32_t)(3 * Q), c->d_q);
+        import_floats_kernel<<<ceil_div(Q, 256), 256, 0, g_stream>>>(c->d_mq + 3 * Q, (uint32_t)Q, c->d_r);
+        PCTCHK(count_dev(c, algo, c->d_q, c->d_r, Q, c->d_count, g_stream));
+        export_results_kernel<<<ceil_div(Q, 256), 256, 0, g_stream>>>(c->d_count, nullptr, (uint32_t)Q, c->d_mi, nullptr, next_signal(c));
+        HIPCHK(hipGetLastError());
+        PCTCHK(express_wait(c));
+        std::memcpy(count, c->h_mi, sizeof(uint32_t) * (size_t)Q);
+        return PCT_OK;
+    }
     HIPCHK(hipMemcpyAsync(c->d_q, q, sizeof(float) * 3 * Q, hipMemcpyHostToDevice, g_stream));
     HIPCHK(hipMemcpyAsync(c->d_r, r, sizeof(float) * Q, hipMemcpyHostToDevice, g_stream));
     PCTCHK(count_dev(c, algo, c->d_q, c->d_r, Q, c->d_count, g_stream));
