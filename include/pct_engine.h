@@ -109,6 +109,14 @@ int pct_cloud_ring_index(pct_cloud *c, float cell_size, const float extent[3]);
 int pct_cloud_ring_drop(pct_cloud *c);
 int pct_cloud_has_ring_index(const pct_cloud *c);
 int pct_cloud_ring_info(pct_cloud *c, int32_t dims[3], double *cell_size, int64_t *overflow_entries);
+/* Zero-copy ingest.  pct_cloud_frame_buffer hands out a host-mapped staging buffer of at least `bytes` bytes (valid until the next
+ * call that asks for a larger one, or pct_cloud_destroy); the producer -- a sensor driver, the deserialiser of a
+ * sensor_msgs/PointCloud2 -- writes the frame's records there (x, y, z floats at the start of each stride-byte record) and
+ * pct_cloud_append_frame appends the first n of them exactly as pct_cloud_append_aos would (rcvPointCloudCallBack,
+ * sim_planning_demo.cpp:159-178), minus the host-side copy: on a rolling-map cloud the insert kernel reads the buffer over the bus. */
+int pct_cloud_frame_buffer(pct_cloud *c, int64_t bytes, void **host_ptr);
+int pct_cloud_append_frame(pct_cloud *c, int64_t n, int64_t stride_bytes);
+
 /* diagnostics (tests): where ring slot `slot`'s record is filed: out = {where word, bucket of the slot's coordinates, head, tail of
  * that bucket (or of the overflow queue, bit 31 of the where word), id word stored at the filed position, overflow queue length} */
 int pct_debug_ring_slot(pct_cloud *c, int64_t slot, uint32_t out[6]);

@@ -121,6 +121,8 @@ struct pct_cloud {
     uint32_t *h_mi = nullptr, *d_mi = nullptr;
     double *h_md = nullptr, *d_md = nullptr;
     int64_t mcap = 0;
+    unsigned char *h_frame = nullptr, *d_frame = nullptr;       // host-mapped staging of appended sensor frames (ring_append)
+    size_t frame_cap = 0;
     uint32_t xseq = 0;
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
     double *h_aux = nullptr, *d_aux = nullptr;
@@ -1137,6 +1139,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     if (c->h_xseq) (void)hipHostFree(c->h_xseq);
+    if (c->h_frame) (void)hipHostFree(c->h_frame);
     if (c->h_mq) (void)hipHostFree(c->h_mq);
     if (c->h_mi) (void)hipHostFree(c->h_mi);
     if (c->h_md) (void)hipHostFree(c->h_md);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void ring_insert_kernel(RingDesc R, float *__r
                                                           const unsigned char *__restrict__ src, uint32_t stride, uint32_t n,
                                                           uint32_t slot0, uint2 *__restrict__ ht, float4 *__restrict__ slots,
                                                           float4 *__restrict__ ovf, uint32_t *__restrict__ where, RingState *__restrict__ st,
-                                                          uint32_t new_count)
+                                                          uint32_t new_count, ExpressSignal sig)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -187,12 +187,16 @@ __global__ __launch_bounds__(256) void ring_insert_kernel(RingDesc R, float *__r
         const uint32_t len = __hip_atomic_load(&st->ovf_tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&R.status[1], len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (i >= n) return;
-    const uint32_t slot = slot0 + i;
-    const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
-    const float px = p[0], py = p[1], pz = p[2];
-    x[slot] = px; y[slot] = py; z[slot] = pz;
-    ring_file(R, px, py, pz, slot, ht, slots, ovf, where, st);
+    // (the frame may sit in host-mapped memory and be read over the bus: fetching the block's records with 16-byte loads into LDS
+    // first was measured and changed nothing -- 600 KB take ~35 us either way, the bus's rate for a transfer this small)
+    if (i < n) {
+        const uint32_t slot = slot0 + i;
+        const float *p = reinterpret_cast<const float *>(src + (size_t)i * stride);
+        const float px = p[0], py = p[1], pz = p[2];
+        x[slot] = px; y[slot] = py; z[slot] = pz;
+        ring_file(R, px, py, pz, slot, ht, slots, ovf, where, st);
+    }
+    express_done_block(sig);       // the append's last launch carries the completion word the host polls (sig.seq == nullptr: nothing)
 }
 
 // file the points already in the SoA arrays (slots [slot0, slot0 + n)) after the tables have been cleared: the index of a

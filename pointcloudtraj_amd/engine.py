@@ -116,6 +116,8 @@ def lib():
         L.pct_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_last_batch_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pct_kernel_ms_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+        L.pct_cloud_frame_buffer.argtypes = [vp, i64, C.POINTER(vp)]
+        L.pct_cloud_append_frame.argtypes = [vp, i64, i64]
         L.pct_debug_read_grid.argtypes = [vp, vp, vp]
         L.pct_set_timing.argtypes = [vp, C.c_int]
         L.pct_set_timing_stride.argtypes = [vp, C.c_int]
@@ -225,6 +227,16 @@ class Cloud:
     def append(self, points):
         a, stride = self._aos(points)
         _chk(lib().pct_cloud_append_aos(self._h, _ptr(a), len(a), stride))
+
+    def frame_buffer(self, n: int, floats_per_point: int = 3):
+        """host-mapped staging buffer for zero-copy appends, as a float32 [n, floats_per_point] array the producer fills in place"""
+        p = C.c_void_p()
+        _chk(lib().pct_cloud_frame_buffer(self._h, int(n) * floats_per_point * 4, C.byref(p)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(int(n), floats_per_point))
+
+    def append_frame(self, n: int, floats_per_point: int = 3):
+        """append the first n records of the frame buffer (pct_cloud_append_frame)"""
+        _chk(lib().pct_cloud_append_frame(self._h, int(n), floats_per_point * 4))
 
     def build_grid(self, cell_size: float = 0.0):
         _chk(lib().pct_cloud_build_grid(self._h, float(cell_size)))

@@ -396,3 +396,27 @@ def test_replan_plan_randomised_shapes(E, oracle):
             assert got["first_hit_sample"] == ref["first_hit_sample"], it
     plan.close()
     c.close()
+
+
+def test_zero_copy_frames_equal_copied_frames(E, oracle):
+    """pct_cloud_frame_buffer / pct_cloud_append_frame (the producer writes into the host-mapped staging buffer) against ordinary
+    appends of the same frames: same window, same answers -- with and without the rolling-map index, across the wrap, interleaved
+    with ordinary appends (which may re-use the same staging buffer)"""
+    for ring in (True, False):
+        cap = 50_000
+        c, m = E.Cloud(cap), Mirror(cap)
+        if ring:
+            c.ring_index()
+        buf = c.frame_buffer(12_000)
+        for k in range(9):
+            n = 12_000 if k % 3 else 7_001
+            f = synth.uniform_points(300 + k, n, 0.0, 25.0, offset=k * 12_000)
+            if k % 4 == 3:
+                c.append(f)                                   # ordinary append in between
+            else:
+                buf[:n] = f
+                c.append_frame(n)
+            m.append(f)
+            q = synth.uniform_points(400 + k, 300, -1.0, 26.0)
+            check_nn(E, c, m, q, oracle, f"ring={ring} frame {k}")
+        c.close()
