@@ -758,3 +758,48 @@ def test_cell_index_structure(E, oracle, shape):
     wi, wd = oracle.brute_nearest(pts, qh)
     assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
     c.close()
+
+
+def test_host_buffer_batches_around_the_mapped_io_threshold(E, oracle):
+    """pct_nn_batch_algo / pct_radius_count_batch_algo move batches of up to 65 536 queries through host-mapped memory (import /
+    export kernels, polled completion) and larger ones by DMA: same answers on both sides of the threshold, for growing and
+    shrinking batch sizes (the staging buffers grow on demand), on the indexed and the brute-force path"""
+    pts = synth.uniform_points(3, 300_000, 0, 40)
+    c = make_cloud(E, pts, grid=True)
+    for Q in (1025, 5000, 65_536, 65_537, 3000, 70_000, 1100):
+        qh = synth.uniform_points(90 + Q % 7, Q, -1, 41)
+        idx, d2 = c.nn(qh, E.ALGO_GRID)
+        cnt = c.radius_count(qh, 0.8, E.ALGO_GRID)
+        m = min(Q, 3000)                                        # the oracle on a sample
+        pick = np.linspace(0, Q - 1, m).astype(np.int64)
+        wi, wd = oracle.brute_nearest(pts, qh[pick])
+        assert np.array_equal(idx[pick], wi) and np.array_equal(d2[pick], wd), Q
+        assert np.array_equal(cnt[pick], oracle.brute_count(pts, qh[pick], 0.8)), Q
+    qh = synth.uniform_points(5, 2048, 0, 40)
+    idx, d2 = c.nn(qh, E.ALGO_STREAM)                           # brute force through the same host-buffer path
+    wi, wd = oracle.brute_nearest(pts, qh)
+    assert np.array_equal(idx, wi) and np.array_equal(d2, wd)
+    assert np.array_equal(c.radius_count(qh, 1.1, E.ALGO_STREAM), oracle.brute_count(pts, qh, 1.1))
+    c.close()
+    empty = E.Cloud(16)
+    with pytest.raises(E.EngineError):
+        empty.nn(qh[:2000])                                     # an empty cloud is an error on the mapped path too
+    empty.close()
+
+
+def test_frame_buffer_and_timing_argument_checks(E):
+    c = E.Cloud(1000)
+    with pytest.raises(E.EngineError):
+        c.append_frame(10)                                      # no buffer handed out yet
+    buf = c.frame_buffer(100)
+    assert buf.shape == (100, 3) and buf.dtype == np.float32
+    with pytest.raises(E.EngineError):
+        c.append_frame(1_000_000)                               # more than the buffer holds
+    with pytest.raises(E.EngineError):
+        c.set_timing_stride(0)
+    buf[:] = synth.uniform_points(1, 100, 0, 1)
+    c.append_frame(100)
+    assert len(c) == 100
+    idx, d2 = c.nn(buf[:5].copy())
+    assert np.array_equal(idx, np.arange(5, dtype=np.uint32)) and np.all(d2 == 0)
+    c.close()
