@@ -47,6 +47,7 @@ def make_case(rng, k):
 
 def test_randomised_paths_agree():
     import torch  # noqa: F401
+    from test_gpu_parity import _check_cell_index
     from pointcloudtraj_amd import engine as E
     from oracle import oracle as O
     E.init(0)
@@ -72,6 +73,7 @@ def test_randomised_paths_agree():
             assert np.array_equal(dm, d1) and np.array_equal(im, i1), name + f" filter mode {mode}"
             assert np.array_equal(cm, cb), name + f" count, filter mode {mode}"
         c.build_grid()
+        _check_cell_index(c, pts)                 # every record in the cell its coordinates map to, cell_start a prefix sum
         i3, d3 = c.nn(q, E.ALGO_GRID)
         cg = c.radius_count(q[:2000], rad[:2000], E.ALGO_GRID)
         assert np.array_equal(d1, d2) and np.array_equal(i1, i2), name + " filter vs all-fp64"
