@@ -596,7 +596,10 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         // no longer pays for its pass (same-box: 0.198-0.204 ms per step with it, 0.168 without).
         static const int levels = [] { const char *e = std::getenv("PCT_SORT_LEVELS"); return e ? std::max(1, std::min(2, std::atoi(e))) : 1; }();
         int lshift = 10;                         // level-1 bucket = key >> 10 (keys < 2^20): finer buckets (key >> 8, >> 9) measured the same
-        if (const char *e = std::getenv("PCT_SORT_LSHIFT")) lshift = std::max(10, std::atoi(e));   // coarser buckets (tuning, single-level mode)
+        if (const char *e = std::getenv("PCT_SORT_LSHIFT")) {           // tuning, single-level mode: finer or coarser buckets (always <= 1024 of them)
+            lshift = std::max(0, std::atoi(e));
+            while (((((uint64_t)B.nbins - 1) >> key_shift) >> lshift) >= (uint64_t)kSortBuckets) lshift++;
+        }
         static const int per_block_env = [] { const char *e = std::getenv("PCT_SORT_PER_BLOCK"); return e ? std::min(kSortPerBlock, std::max(1024, std::atoi(e) / 1024 * 1024)) : 0; }();
         // ~128 blocks: small batches want parallelism (64 K queries: 21 us at 1024 per block, 36 us at 8192), large ones
         // want long per-block bucket slices (1 M: 67 us at 8192, 87 us at 1024)
