@@ -91,7 +91,10 @@ int pct_cloud_upload_fields(pct_cloud *c, const void *data, int64_t n, int64_t p
 /* Same, from three device arrays (already SoA, e.g. produced on the GPU). */
 int pct_cloud_upload_soa_dev(pct_cloud *c, const float *d_x, const float *d_y, const float *d_z, int64_t n);
 /* Rolling map: append n points, overwriting the oldest once capacity is reached (ring).
- * Index of a point = its slot in the ring.  Drops any cell-sorted grid; updates the rolling-map index in place. */
+ * Index of a point = its slot in the ring.  Drops any cell-sorted grid; updates the rolling-map index in place.
+ * `pts` is the caller's again when the call returns.  On a rolling-map cloud a frame of up to 4 MB is copied to a staging buffer
+ * and the call returns once the launches are queued (every later call on the cloud is ordered behind them on the library's
+ * stream); an error of those launches is reported by the next call on the cloud. */
 int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t stride_bytes);
 
 /* Rolling-map index (config C5: the obstacle map is a sliding window fed one sensor frame at a time, where the reference

@@ -123,6 +123,9 @@ struct pct_cloud {
     int64_t mcap = 0;
     unsigned char *h_frame = nullptr, *d_frame = nullptr;       // host-mapped staging of appended sensor frames (ring_append)
     size_t frame_cap = 0;
+    unsigned char *h_astage = nullptr, *d_astage = nullptr;     // the library's own staging of copied frames
+    size_t astage_cap = 0;
+    bool append_pending = false;                                // ring_append returned before its insert kernel finished (ring_host.inc)
     uint32_t xseq = 0;
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
     double *h_aux = nullptr, *d_aux = nullptr;
@@ -1143,6 +1146,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     if (c->h_xseq) (void)hipHostFree(c->h_xseq);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
+    if (c->h_astage) (void)hipHostFree(c->h_astage);
     if (c->h_mq) (void)hipHostFree(c->h_mq);
     if (c->h_mi) (void)hipHostFree(c->h_mi);
     if (c->h_md) (void)hipHostFree(c->h_md);
