@@ -125,6 +125,8 @@ struct pct_cloud {
     size_t frame_cap = 0;
     unsigned char *h_astage = nullptr, *d_astage = nullptr;     // the library's own staging of copied frames
     size_t astage_cap = 0;
+    hipEvent_t ev_mut = nullptr;                                // recorded on the library's stream behind an asynchronous mutation
+    bool mut_pending = false;                                   // ... which a call on another stream has to order itself behind
     bool append_pending = false;                                // ring_append returned before its insert kernel finished (ring_host.inc)
     uint32_t xseq = 0;
     // fused RRT* expansion (small clouds = node sets): per-node {x, y, z, radius} as the planner holds them, and the results
@@ -293,6 +295,26 @@ bool mapped_io_on()
     return on && poll_results();
 }
 
+// Rolling-map appends and index builds return once their launches are queued on the library's stream.  Calls on that stream are
+// ordered behind them by construction; a *_dev call on the caller's own stream waits on this event (until it has been seen complete).
+int note_mutation(pct_cloud *c)
+{
+    if (!c->ev_mut) HIPCHK(hipEventCreateWithFlags(&c->ev_mut, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_mut, g_stream));
+    c->mut_pending = true;
+    return PCT_OK;
+}
+
+int order_after_mutations(pct_cloud *c, hipStream_t s)
+{
+    if (!c->mut_pending || s == g_stream) return PCT_OK;
+    const hipError_t q = hipEventQuery(c->ev_mut);
+    if (q == hipSuccess) { c->mut_pending = false; return PCT_OK; }
+    if (q != hipErrorNotReady) return fail(PCT_ERR_HIP, "hipEventQuery -> %s", hipGetErrorString(q));
+    HIPCHK(hipStreamWaitEvent(s, c->ev_mut, 0));
+    return PCT_OK;
+}
+
 int require_init()
 {
     if (g_device < 0) return pct_init(0);
@@ -383,7 +405,8 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
             else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        // no synchronise: the scratch stays with the cloud and every consumer of the index is ordered behind these launches on the
+        // library's stream (a launch failure is reported by the next call that synchronises)
         if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
         return PCT_OK;
     }
@@ -1145,6 +1168,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_xr) (void)hipHostFree(c->h_xr);
     if (c->h_xids) (void)hipHostFree(c->h_xids);
     if (c->h_xseq) (void)hipHostFree(c->h_xseq);
+    if (c->ev_mut) (void)hipEventDestroy(c->ev_mut);
     if (c->h_frame) (void)hipHostFree(c->h_frame);
     if (c->h_astage) (void)hipHostFree(c->h_astage);
     if (c->h_mq) (void)hipHostFree(c->h_mq);
@@ -1440,19 +1464,21 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     c->B = B;
     c->has_grid = true;
     c->generation++;
-    return PCT_OK;
+    return note_mutation(c);       // the build's launches may still be running (sort_into_cells): *_dev calls on other streams wait for them
 }
 
 // ---- device-buffer entry points --------------------------------------------------------
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream)
 {
     if (!c || Q < 0 || (Q > 0 && (!d_q || !d_idx || !d_d2))) return fail(PCT_ERR_INVALID, "bad nn_batch_dev arguments");
+    PCTCHK(order_after_mutations(c, (hipStream_t)stream));
     return nn_dev(c, algo, d_q, Q, d_idx, d_d2, (hipStream_t)stream);   // NULL = HIP's null stream (torch's default stream)
 }
 
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream)
 {
     if (!c || Q < 0 || (Q > 0 && (!d_q || !d_r || !d_count))) return fail(PCT_ERR_INVALID, "bad radius_count_batch_dev arguments");
+    PCTCHK(order_after_mutations(c, (hipStream_t)stream));
     return count_dev(c, algo, d_q, d_r, Q, d_count, (hipStream_t)stream);
 }
 
@@ -1975,6 +2001,7 @@ int pct_inflate_batch_dev(pct_cloud *c, const pct_inflate_params *p, const doubl
     if (!c || !p || Q < 0 || (Q > 0 && (!d_pts || !d_radius))) return fail(PCT_ERR_INVALID, "bad inflate_batch_dev arguments");
     if (Q == 0) return PCT_OK;
     if (Q > c->qcap) return fail(PCT_ERR_INVALID, "batch of %lld exceeds reserved %lld (call pct_cloud_reserve_queries)", (long long)Q, (long long)c->qcap);
+    PCTCHK(order_after_mutations(c, (hipStream_t)stream));
     return inflate_dev(c, p, Q, (hipStream_t)stream, d_pts, nullptr, d_radius, d_idx, d_d2);
 }
 
@@ -1992,6 +2019,7 @@ int pct_bezier_check_dev(pct_cloud *c, const pct_bezier_traj *traj, const pct_in
             return fail(PCT_ERR_INVALID, "segment %d: order %d unsupported", i, traj->orders[i]);
     const size_t ncoef = (size_t)traj->nseg * traj->row_stride;
     hipStream_t s = (hipStream_t)stream;
+    PCTCHK(order_after_mutations(c, s));
     if (ncoef > c->coef_cap || (size_t)traj->nseg > c->seg_cap) {       // grow the coefficient buffers (earlier work may still read the old ones)
         HIPCHK(hipDeviceSynchronize());
         if (ncoef > c->coef_cap) { dev_free(c->d_coef); c->coef_cap = 0; PCTCHK(dev_alloc(&c->d_coef, ncoef)); c->coef_cap = ncoef; }
