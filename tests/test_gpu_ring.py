@@ -420,3 +420,43 @@ def test_zero_copy_frames_equal_copied_frames(E, oracle):
             q = synth.uniform_points(400 + k, 300, -1.0, 26.0)
             check_nn(E, c, m, q, oracle, f"ring={ring} frame {k}")
         c.close()
+
+
+def test_device_calls_on_other_streams_follow_asynchronous_mutations(E, oracle):
+    """pct_cloud_append_aos (rolling map) and pct_cloud_build_grid return once their launches are queued on the library's stream; a
+    *_dev call issued right away on ANOTHER stream must still see the finished index (it waits on the cloud's mutation event)"""
+    import torch
+    side = torch.cuda.Stream()
+    # rolling map: big frames, query on the side stream immediately after each append
+    cap = 600_000
+    c, m = E.Cloud(cap), Mirror(cap)
+    c.ring_index(0.0, (40.0, 40.0, 40.0))
+    c.reserve_queries(4096)
+    qh = synth.uniform_points(500, 4096, 0.0, 40.0)
+    with torch.cuda.stream(side):
+        q = torch.from_numpy(qh).cuda()
+        idx = torch.empty(len(qh), dtype=torch.int32, device="cuda")
+        d2 = torch.empty(len(qh), dtype=torch.float64, device="cuda")
+    side.synchronize()
+    for k in range(5):
+        f = synth.uniform_points(510 + k, 200_000, 0.0, 40.0)
+        c.append(f)                                              # returns with the insert kernel still running
+        c.nn_device(q.data_ptr(), len(qh), idx.data_ptr(), d2.data_ptr(), side.cuda_stream, E.ALGO_AUTO)
+        side.synchronize()
+        m.append(f)
+        wi, wd = oracle.brute_nearest_mt(m.live(), qh)            # index of a point = its ring slot = its row in the mirror
+        assert np.array_equal(d2.cpu().numpy(), wd), f"frame {k}"
+        assert np.array_equal(idx.cpu().numpy().view(np.uint32).astype(np.int64), wi.astype(np.int64)), f"frame {k}"
+    c.close()
+    # cell-sorted index: build, then query on the side stream at once
+    pts = synth.uniform_points(520, 3_000_000, 0.0, 60.0)
+    c = E.Cloud(len(pts))
+    c.set_input(pts)
+    c.reserve_queries(4096)
+    for _ in range(3):
+        c.build_grid()
+        c.nn_device(q.data_ptr(), len(qh), idx.data_ptr(), d2.data_ptr(), side.cuda_stream, E.ALGO_GRID)
+        side.synchronize()
+        wi, wd = oracle.brute_nearest_mt(pts, qh)
+        assert np.array_equal(d2.cpu().numpy(), wd) and np.array_equal(idx.cpu().numpy().view(np.uint32).astype(np.int64), wi.astype(np.int64))
+    c.close()
