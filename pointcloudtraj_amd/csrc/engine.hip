@@ -910,18 +910,26 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
             const bool so = perm != nullptr && sorted_writes && lds_sort_on();
             uint32_t *k_idx = so ? c->d_sres_idx : d_idx;
             double *k_d2 = so ? c->d_sres_d2 : d_d2;
-            if (c->count_work)
-                nn_grid_coop_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
-                                                                  perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
-            else if (c->dom_valid && dom_ext_on()) {
+            // wave-cooperative fallback for the queries the 2x2x2 block leaves undecided (kernels.hpp, default) or the 8-lane cube
+            static const bool wave_cube = [] { const char *e = std::getenv("PCT_COOP_WAVE_CUBE"); return e ? std::atoi(e) != 0 : true; }();
+            const float4 *recs = perm ? c->d_qsorted : nullptr;
+            if (c->count_work) {
+                if (wave_cube) nn_grid_coop_kernel<true, true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                else nn_grid_coop_kernel<true, false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+            } else if (c->dom_valid && dom_ext_on()) {
                 // the kernel's own begin / end timestamps (hipExtLaunchKernel): no marker packets on the stream -- the two
                 // hipEventRecord calls of dom_begin / dom_end cost ~10 us of a 160 us step
-                hipExtLaunchKernelGGL(nn_grid_coop_kernel<false>, dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->sorted, c->cell_start, d_q,
-                                      (uint32_t)Q, (uint32_t)c->index_base, perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                if (wave_cube)
+                    hipExtLaunchKernelGGL((nn_grid_coop_kernel<false, true>), dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->sorted, c->cell_start, d_q,
+                                          (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                else
+                    hipExtLaunchKernelGGL((nn_grid_coop_kernel<false, false>), dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->sorted, c->cell_start, d_q,
+                                          (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
                 dom_done(c);
-            } else
-                nn_grid_coop_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base,
-                                                                   perm ? c->d_qsorted : nullptr, k_idx, k_d2, c->d_work, so ? 1 : 0);
+            } else if (wave_cube)
+                nn_grid_coop_kernel<false, true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+            else
+                nn_grid_coop_kernel<false, false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
             if (so) {
                 dom_end(c, s);
                 unpermute_results_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(c->d_inv, c->d_sres_idx, c->d_sres_d2, (uint32_t)Q, d_idx, d_d2);

@@ -1622,8 +1622,162 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
     }
 }
 
+// ---- the same search with a WAVE-cooperative fallback (the batch kernel's default) -------------------------------------------
+// Stage 0 decides ~99 % of the queries at 6 points per cell, but a wave holds 8 queries and used to run the 3x3x3 cube for all of
+// them -- 8 lanes per query, the 9 rows of ~18 points taken 8 at a time -- as soon as ONE was undecided: 0.99^8 = 8 % of the waves,
+// 15 % of the kernel's time (18 of 124 us on the 10 M-point cloud).  Here the whole wave turns to each undecided query in turn:
+// 9 lanes fetch the rows' bounds, every lane takes one point of each row (all nine loads in flight), one 6-step fold over the 64
+// lanes, the exact winner.  The queries that even the cube does not decide (~1e-4) finish with the 8-lane shell walk as before.
+
+// stage 0 of coop_nn_search alone; returns true when the query is still undecided
 template <bool COUNT>
-__global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
+__device__ __forceinline__ bool coop_stage0(const GridDesc &G, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                            float qxf, float qyf, float qzf, uint32_t sub, double &bd, uint32_t &bi, uint32_t &npts,
+                                            uint32_t &nruns)
+{
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+    const float fx = (qxf - G.ox) * G.inv_h - (float)cx, fy = (qyf - G.oy) * G.inv_h - (float)cy, fz = (qzf - G.oz) * G.inv_h - (float)cz;
+    const int xa = max(fx < 0.5f ? cx - 1 : cx, 0), xb = min(fx < 0.5f ? cx : cx + 1, G.gx - 1);
+    const int ya = max(fy < 0.5f ? cy - 1 : cy, 0), yb = min(fy < 0.5f ? cy : cy + 1, G.gy - 1);
+    const int za = max(fz < 0.5f ? cz - 1 : cz, 0), zb = min(fz < 0.5f ? cz : cz + 1, G.gz - 1);
+    uint32_t rs[4], re[4];
+    {
+        const int ri = (int)sub & 3;                              // lanes 4..7 repeat lanes 0..3 (same addresses: no extra access)
+        const bool ok = !((ri >> 1) && zb == za) && !((ri & 1) && yb == ya);
+        const uint32_t row = cell_lin(G, 0, (ri & 1) ? yb : ya, (ri >> 1) ? zb : za);
+        const uint32_t a = cell_start[row + xa], b = cell_start[row + xb + 1];
+        const uint32_t my_s = a, my_e = ok ? b : a;
+        if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
+    }
+    coop_screen_rows<4, 2>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+    double bound = __builtin_huge_val();
+    if (xa > 0) bound = fmin(bound, qx - (G.oxd + (double)xa * G.hd));
+    if (xb < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(xb + 1) * G.hd) - qx);
+    if (ya > 0) bound = fmin(bound, qy - (G.oyd + (double)ya * G.hd));
+    if (yb < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(yb + 1) * G.hd) - qy);
+    if (za > 0) bound = fmin(bound, qz - (G.ozd + (double)za * G.hd));
+    if (zb < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(zb + 1) * G.hd) - qz);
+    if (bound == __builtin_huge_val()) return false;              // the block covers the whole grid
+    bound -= G.hd * (1.0 / 256.0);                                // same slack as cube_bound (fp32 cell assignment)
+    return !(bound > 0.0 && bd <= bound * bound);
+}
+
+// the 3x3x3 cube around the cell of a WAVE-UNIFORM query, searched by all 64 lanes; every lane returns the same exact (bd, bi)
+// = the winner by (d2, index) among the cube's points, (+inf, none) for an empty cube
+template <bool COUNT>
+__device__ __forceinline__ void wave_cube_search(const GridDesc &G, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                                 float qxf, float qyf, float qzf, double &bd, uint32_t &bi, uint32_t &npts, uint32_t &nruns)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.gx - 1);
+    uint32_t my_s, my_e;
+    {
+        const int l = lane < 9 ? (int)lane : 0;                       // lanes 9.. repeat lane 0's addresses
+        const int zz = cz + l / 3 - 1, yy = cy + l % 3 - 1;
+        const bool ok = zz >= 0 && zz < G.gz && yy >= 0 && yy < G.gy;
+        const uint32_t row = ok ? cell_lin(G, 0, yy, zz) : 0u;
+        const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
+        my_s = a;
+        my_e = ok ? b : a;
+        if (COUNT && lane < 9) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
+    }
+    uint32_t rs[9], re[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {                                     // wave-uniform: scalar registers
+        rs[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_s, k);
+        re[k] = (uint32_t)__builtin_amdgcn_readlane((int)my_e, k);
+    }
+    float m1 = __builtin_huge_valf(), m2 = __builtin_huge_valf();
+    uint32_t p1 = 0;
+    float4 P[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const uint32_t a = rs[k], b = re[k];
+        P[k] = pts[min(a + lane, b > a ? b - 1 : 0u)];                // empty row / lane beyond the row: any valid slot, masked below
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const uint32_t p = rs[k] + lane;
+        const float dx = P[k].x - qxf, dy = P[k].y - qyf, dz = P[k].z - qzf;
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+        d = (p < re[k]) ? d : __builtin_huge_valf();
+        const bool lt = d < m1;
+        m2 = lt ? m1 : fminf(m2, d);
+        p1 = lt ? p : p1;
+        m1 = fminf(m1, d);
+    }
+#pragma unroll 1
+    for (int k = 0; k < 9; k++)                                       // rows of more than 64 points
+        for (uint32_t p = rs[k] + 64u + lane; p < re[k]; p += 64u) {
+            const float4 Pp = pts[p];
+            const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
+            const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            const bool lt = d < m1;
+            m2 = lt ? m1 : fminf(m2, d);
+            p1 = lt ? p : p1;
+            m1 = fminf(m1, d);
+        }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {                          // (smallest, runner-up, position) over the wave
+        const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
+        const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
+        const bool lt = o1 < m1;
+        m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
+        p1 = lt ? op : p1;
+        m1 = fminf(m1, o1);
+    }
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
+    if (m1 < __builtin_huge_valf()) {                                 // wave-uniform
+        if (m2 > m1 * (1.0f + 0x1p-19f) + 0x1p-90f) {                // unique within the fp32 error band: it is the exact winner
+            const float4 W = pts[p1];
+            bd = dist2((double)W.x, (double)W.y, (double)W.z, qx, qy, qz);
+            bi = __float_as_uint(W.w);
+        } else {                                                      // near-ties / duplicates: exact (d2, index) order decides
+#pragma unroll 1
+            for (int k = 0; k < 9; k++)
+                for (uint32_t p = rs[k] + lane; p < re[k]; p += 64u) {
+                    const float4 Pp = pts[p];
+                    const double d2 = dist2((double)Pp.x, (double)Pp.y, (double)Pp.z, qx, qy, qz);
+                    const uint32_t id = __float_as_uint(Pp.w);
+                    if (better(d2, id, bd, bi)) { bd = d2; bi = id; }
+                }
+            wave_argmin(bd, bi);
+        }
+    }
+}
+
+// after the cube: shells of growing radius until the termination bound holds (8 lanes per query, rare on dense clouds)
+template <bool COUNT>
+__device__ __forceinline__ void coop_finish_shells(const GridDesc &G, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
+                                                   float qxf, float qyf, float qzf, uint32_t sub, double &bd, uint32_t &bi, uint32_t &npts,
+                                                   uint32_t &nruns)
+{
+    const double qx = (double)qxf, qy = (double)qyf, qz = (double)qzf;
+    const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx);
+    const int cy = cell_coord(qyf, G.oy, G.inv_h, G.gy);
+    const int cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+    for (int r = 1;; r++) {
+        if (r > 1) {
+            coop_scan_cube_or_shell<COUNT>(G, pts, cell_start, cx, cy, cz, r, false, sub, qx, qy, qz, bd, bi, npts, nruns);
+            coop_argmin8(bd, bi);
+        }
+        const double bound = cube_bound(G, cx, cy, cz, r, qx, qy, qz);
+        if (bound == __builtin_huge_val() || (bound > 0.0 && bd <= bound * bound)) break;
+    }
+}
+
+template <bool COUNT, bool WAVE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                            const uint32_t *__restrict__ cell_start,
                                                            const float *__restrict__ q, uint32_t Q, uint32_t index_base,
                                                            const float4 *__restrict__ qsorted,
@@ -1634,7 +1788,40 @@ __global__ __launch_bounds__(256) void nn_grid_coop_kernel(GridDesc G, const flo
     const uint32_t bslot = qsorted ? xcd_contiguous_block(blockIdx.x, gridDim.x) : blockIdx.x;
     const uint32_t slot = bslot * (256 / kCoop) + (threadIdx.x / kCoop);
     uint32_t npts = 0, nruns = 0;
-    if (slot < Q) {                                   // uniform within a group of 8 lanes
+    if (WAVE && G.octant_first) {                     // wave-cooperative fallback (see above); every lane of the wave stays in step
+        const bool live = slot < Q;
+        uint32_t t = slot;
+        float qxf = 0.0f, qyf = 0.0f, qzf = 0.0f;
+        if (live) {
+            if (qsorted) {
+                const float4 R = qsorted[slot];
+                qxf = R.x; qyf = R.y; qzf = R.z; t = sorted_out ? slot : __float_as_uint(R.w);
+            } else {
+                qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
+            }
+        }
+        double bd = __builtin_huge_val();
+        uint32_t bi = kNoIndex;
+        bool undecided = false;
+        if (live) undecided = coop_stage0<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(undecided && sub == 0);
+        while (todo) {                                // wave-uniform: one undecided query at a time, all 64 lanes on it
+            const int g = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float bx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qxf), g)),
+                        by = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qyf), g)),
+                        bz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qzf), g));
+            double cbd;
+            uint32_t cbi;
+            wave_cube_search<COUNT>(G, pts, cell_start, bx, by, bz, cbd, cbi, npts, nruns);
+            if (((threadIdx.x & 63) >> 3) == (uint32_t)(g >> 3)) { bd = cbd; bi = cbi; }
+        }
+        if (live && undecided) coop_finish_shells<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
+        if (live && sub == 0) {
+            out_idx[t] = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+            out_d2[t] = bd;
+        }
+    } else if (slot < Q) {                            // uniform within a group of 8 lanes
         uint32_t t = slot;
         float qxf, qyf, qzf;
         if (qsorted) {                                // binned batch: query and output slot in one record
