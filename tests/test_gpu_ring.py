@@ -423,8 +423,9 @@ def test_zero_copy_frames_equal_copied_frames(E, oracle):
 
 
 def test_device_calls_on_other_streams_follow_asynchronous_mutations(E, oracle):
-    """pct_cloud_append_aos (rolling map) and pct_cloud_build_grid return once their launches are queued on the library's stream; a
-    *_dev call issued right away on ANOTHER stream must still see the finished index (it waits on the cloud's mutation event)"""
+    """pct_cloud_append_aos on a rolling map returns once its launches are queued on the library's stream; a *_dev call issued right
+    away on ANOTHER stream must still see the finished index (it waits on the cloud's mutation event).  pct_cloud_build_grid is
+    synchronous; the same pattern is checked for it."""
     import torch
     side = torch.cuda.Stream()
     # rolling map: big frames, query on the side stream immediately after each append
