@@ -53,7 +53,7 @@ def measured_traffic(kernel: str):
         except (OSError, ValueError):
             continue
         for k, v in d.items():
-            if kernel in k and "<true>" not in k and "derived_hbm_traffic_bytes_per_launch" in v:   # <true> = instrumented twin
+            if kernel in k and "kernel<true" not in k and "derived_hbm_traffic_bytes_per_launch" in v:   # <true, ...> = instrumented twin
                 best, src = v["derived_hbm_traffic_bytes_per_launch"], "profiles/" + os.path.basename(f)
     return best, src
 
