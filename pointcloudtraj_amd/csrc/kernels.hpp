@@ -1100,21 +1100,22 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDes
         for (int k = 0; k < kSortItems; k++)
             if (key[k] != 0xFFFFFFFFu) key[k] = query_bin(G, B, qv[k][0], qv[k][1], qv[k][2]) >> key_shift;
     }
+    // the histogram atomic's return value IS the query's rank inside (block, bucket): one LDS atomic per query, not two
+    uint32_t rank[kSortItems];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++)
-        if (key[k] != 0xFFFFFFFFu) atomicAdd(&h[key[k] >> lshift], 1u);
+        if (key[k] != 0xFFFFFFFFu) rank[k] = atomicAdd(&h[key[k] >> lshift], 1u);
     __syncthreads();
     {
         const uint32_t mine = h[threadIdx.x];
         basepos[threadIdx.x] = mine ? start + atomicAdd(&fill1[threadIdx.x], mine) : 0u;   // this block's slice of the bucket
-        h[threadIdx.x] = 0;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         if (key[k] != 0xFFFFFFFFu) {
             const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
-            const uint32_t pos = basepos[key[k] >> lshift] + atomicAdd(&h[key[k] >> lshift], 1u);
+            const uint32_t pos = basepos[key[k] >> lshift] + rank[k];
             if (!final_level) tmp_key[pos] = key[k];  // a fine pass follows and needs the key
             else if (perm) perm[pos] = t;             // single-level mode: this IS the final order; perm only for the kernels that read it
             if (inv) inv[t] = pos;                    // where query t went (coalesced): results come back through it
