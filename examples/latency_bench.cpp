@@ -78,6 +78,11 @@ int main(int argc, char **argv)
         int64_t k = 0;
         lat("pct_cloud_append_aos, 50,000-point frame into the 5 M-point rolling map", [&] { pct_cloud_append_aos(ring, cloud.data() + 3 * ((k++ * F) % (W - F)), F, 12); }, 300);
         lat("pct_plan_replan_run: 64 nodes + 99 samples + 21 control points, one graph", [&] { pct_plan_replan_run(plan, &prm, batch.data(), 64, &tr, 0.0, 2.0, 0.02, 0, &out); });
+        // one whole tick: the append returns once its launches are queued, the graph queues behind the insert kernel
+        lat("C5 tick: pct_cloud_append_aos (50,000 points) + pct_plan_replan_run", [&] {
+            pct_cloud_append_aos(ring, cloud.data() + 3 * ((k++ * F) % (W - F)), F, 12);
+            pct_plan_replan_run(plan, &prm, batch.data(), 64, &tr, 0.0, 2.0, 0.02, 0, &out);
+        }, 300);
         pct_plan_destroy(plan);
         pct_cloud_destroy(ring);
     }
