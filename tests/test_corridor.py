@@ -45,7 +45,7 @@ def test_oracle_corridor_c1(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("speculation,fused", [(1, True), (8, True), (64, True), (8, False), (64, False)])
+@pytest.mark.parametrize("speculation,fused", [(1, True), (8, True), (64, True), (256, True), (8, False), (64, False), (256, False)])
 def test_gpu_corridor_matches_oracle(oracle, speculation, fused):
     """speculation = samples per GPU round trip, fused = one launch per batch (nearest -> steer -> inflation -> range in one
     kernel) or three; every setting must give the one-by-one corridor"""
@@ -89,7 +89,7 @@ def test_oracle_commit_scenario_moves_the_root(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("speculation", [1, 64])
+@pytest.mark.parametrize("speculation", [1, 64, 256])
 def test_gpu_commit_scenario_matches_oracle(oracle, speculation):
     """resetRoot / setStartPt / Refine / Evaluate in the planner's incremental order: corridor, radii, node and query counts equal the
     independent CPU restatement's after every phase"""
