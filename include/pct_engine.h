@@ -220,7 +220,9 @@ int pct_ctrl_points_check(pct_cloud *c, const pct_bezier_traj *traj, const pct_i
  * stream, as in any HIP call -- that is also PyTorch's default stream).  Every kernel of the batch is
  * ordered on that stream and nothing else, so work the caller queues behind it (a collective, a copy)
  * sees the results.  One batch at a time per cloud: the cloud's scratch buffers are shared, so do not
- * issue batches on the same cloud from two streams concurrently.  For torch.distributed sharding and
+ * issue batches on the same cloud from two streams concurrently.  A rolling-map append that is still running on the library's
+ * own stream (pct_cloud_append_aos returns once its launches are queued) is waited for through an event, so a batch issued right
+ * after it on `stream` sees the appended frame.  For torch.distributed sharding and
  * graph capture.  An empty shard yields idx=PCT_NO_INDEX, d2=+inf and PCT_OK. ---------------------- */
 int pct_nn_batch_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
 int pct_radius_count_batch_dev(pct_cloud *c, int algo, const float *d_q, const float *d_r, int64_t Q, uint32_t *d_count, void *stream);
