@@ -394,6 +394,52 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
             PCTCHK(dev_alloc(&c->gb_small, small_need));
             c->gb_small_cap = small_need;
         }
+        // level 1 in two passes of fan-out <= 128 when there are many slabs (gridbuild.hpp): pass A sorts by super-slab into the final
+        // array (unused until level 2 writes it), pass B by slab inside every super-slab's region into gb_tmp
+        static const bool two_pass_on = [] { const char *e = std::getenv("PCT_GB_TWO_PASS"); return e ? std::atoi(e) != 0 : true; }();
+        uint32_t two_pass_min = 4096;                 // read per build: the tests lower it to reach this path with small clouds
+        if (const char *e = std::getenv("PCT_GB_TWO_PASS_MIN_SLABS")) two_pass_min = (uint32_t)std::max(2, std::atoi(e));
+        if (two_pass_on && D.nslabs >= two_pass_min) {
+            Gb2Desc DB{};
+            DB.s1 = s1;
+            int lg = 0;
+            while ((1u << lg) < D.nslabs) lg++;
+            DB.sb = std::min(7, (lg + 1) / 2);
+            DB.nslabs = D.nslabs;
+            DB.nsuper = (D.nslabs + (1u << DB.sb) - 1) >> DB.sb;
+            DB.parts = std::max<uint32_t>(1, 512u / DB.nsuper);
+            GbDesc DA = D;
+            DA.s1 = s1 + DB.sb;
+            DA.nslabs = DB.nsuper;
+            const size_t nsub = (size_t)1 << DB.sb;
+            const size_t need2 = (size_t)blocks * DA.nslabs + 3 * (size_t)DA.nslabs + 8 + (size_t)DB.nsuper * DB.parts * nsub + 3 * (size_t)D.nslabs + 8;
+            if (need2 > c->gb_small_cap) {
+                dev_free(c->gb_small);
+                c->gb_small_cap = 0;
+                PCTCHK(dev_alloc(&c->gb_small, need2));
+                c->gb_small_cap = need2;
+            }
+            uint32_t *tableA = c->gb_small, *super_total = tableA + (size_t)blocks * DA.nslabs, *super_cursor = super_total + DA.nslabs,
+                     *super_start = super_cursor + DA.nslabs, *table2 = super_start + DA.nslabs + 1,
+                     *slab_total = table2 + (size_t)DB.nsuper * DB.parts * nsub, *slab_cursor = slab_total + D.nslabs, *slab_start = slab_cursor + D.nslabs;
+            hipError_t e = hipMemsetAsync(super_total, 0, sizeof(uint32_t) * 2 * DA.nslabs, s);
+            if (e == hipSuccess) e = hipMemsetAsync(slab_total, 0, sizeof(uint32_t) * 2 * D.nslabs, s);
+            if (e == hipSuccess) {
+                const size_t ldsA = sizeof(uint32_t) * ((size_t)DA.nslabs + 1);
+                gb_hist_kernel<<<blocks, kGbThreads, ldsA, s>>>(G, DA, c->x, c->y, c->z, (uint32_t)n, tableA, super_total);
+                gb_scatter_kernel<<<blocks, kGbThreads, ldsA, s>>>(G, DA, c->x, c->y, c->z, (uint32_t)n, tableA, super_total, super_cursor, super_start, *sorted);
+                const dim3 g2(DB.parts, DB.nsuper);
+                gb_hist2_kernel<<<g2, kGbThreads, 0, s>>>(G, DB, super_start, *sorted, table2, slab_total);
+                gb_scatter2_kernel<<<g2, kGbThreads, 0, s>>>(G, DB, super_start, *sorted, table2, slab_total, slab_cursor, slab_start, (uint32_t)n, c->gb_tmp);
+                if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+                else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+                else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
+            return PCT_OK;
+        }
         uint32_t *table = c->gb_small, *slab_total = table + (size_t)blocks * D.nslabs, *slab_cursor = slab_total + D.nslabs,
                  *slab_start = slab_cursor + D.nslabs;
         hipError_t e = hipMemsetAsync(slab_total, 0, sizeof(uint32_t) * 2 * D.nslabs, s);

@@ -126,6 +126,79 @@ __global__ __launch_bounds__(kGbThreads) void gb_scatter_kernel(GridDesc G, GbDe
     }
 }
 
+// ---- level 1 in TWO passes for large clouds --------------------------------------------------------------------------------------
+// One pass into thousands of slabs keeps thousands of 16-byte write streams open per block: the lines leave L2 half filled
+// (WRITE_SIZE 2x the bytes, 1.7 TB/s of fabric traffic at 100 M points).  With a fan-out of at most 128 per pass the open lines of
+// all blocks fit the L2s and every line is written once: pass A = the kernels above with slab := SUPER-slab (2^sb consecutive slabs),
+// records into the (still unused) final array; pass B below = the same thing inside every super-slab's region, into `tmp`, in the
+// slab order level 2 expects.  Block (x, S) of pass B handles chunk x of super-slab S's region.  Measured: 100 M points 4.29 -> 3.95 ms
+// (pass A 0.21 + 0.99, pass B 0.31 + 1.16 ms against 0.23 + 2.7 ms for the single pass), 10 M points the same either way (0.39 ms:
+// 22 + 58 + 27 + 97 us against 24 + 183) -- used from 4096 slabs (~16 M points) upwards.
+struct Gb2Desc {
+    int s1, sb;            // slab = cell >> s1, super-slab = slab >> sb
+    uint32_t nslabs, nsuper, parts;    // parts = blocks per super-slab
+};
+
+__global__ __launch_bounds__(kGbThreads) void gb_hist2_kernel(GridDesc G, Gb2Desc D, const uint32_t *__restrict__ super_start,
+                                                              const float4 *__restrict__ recs, uint32_t *__restrict__ table2,
+                                                              uint32_t *__restrict__ slab_total)
+{
+    __shared__ uint32_t h[128];
+    const uint32_t S = blockIdx.y, nsub = 1u << D.sb;
+    if (threadIdx.x < nsub) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t r0 = super_start[S], r1 = super_start[S + 1];
+    const uint32_t chunk = (r1 - r0 + D.parts - 1) / D.parts;
+    const uint32_t b0 = min(r1, r0 + blockIdx.x * chunk), b1 = min(r1, b0 + chunk);
+    for (uint32_t i = b0 + threadIdx.x; i < b1; i += kGbThreads) {   // (four records in flight per thread measured the same)
+        const float4 P = recs[i];
+        atomicAdd(&h[(gb_cell(G, P.x, P.y, P.z) >> D.s1) - (S << D.sb)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < nsub) {
+        const uint32_t v = h[threadIdx.x];
+        table2[((size_t)S * D.parts + blockIdx.x) * nsub + threadIdx.x] = v;
+        const uint32_t slab = (S << D.sb) + threadIdx.x;
+        if (v && slab < D.nslabs) atomicAdd(&slab_total[slab], v);
+    }
+}
+
+__global__ __launch_bounds__(kGbThreads) void gb_scatter2_kernel(GridDesc G, Gb2Desc D, const uint32_t *__restrict__ super_start,
+                                                                 const float4 *__restrict__ recs, const uint32_t *__restrict__ table2,
+                                                                 const uint32_t *__restrict__ slab_total, uint32_t *__restrict__ slab_cursor,
+                                                                 uint32_t *__restrict__ slab_start, uint32_t n, float4 *__restrict__ tmp)
+{
+    __shared__ uint32_t base[128 + 1];
+    __shared__ uint32_t s_wave[kGbThreads / 64], s_carry;
+    const uint32_t S = blockIdx.y, nsub = 1u << D.sb;
+    const uint32_t r0 = super_start[S], r1 = super_start[S + 1];
+    if (threadIdx.x < nsub) {
+        const uint32_t slab = (S << D.sb) + threadIdx.x;
+        base[threadIdx.x] = slab < D.nslabs ? slab_total[slab] : 0u;
+    }
+    __syncthreads();
+    gb_block_scan<kGbThreads>(base, nsub, s_wave, &s_carry);         // exclusive scan of this super-slab's slab sizes
+    if (blockIdx.x == 0) {                                           // publish the slabs' global starts for level 2
+        if (threadIdx.x < nsub) {
+            const uint32_t slab = (S << D.sb) + threadIdx.x;
+            if (slab < D.nslabs) slab_start[slab] = r0 + base[threadIdx.x];
+        }
+        if (S == D.nsuper - 1 && threadIdx.x == 0) slab_start[D.nslabs] = n;
+    }
+    if (threadIdx.x < nsub) {
+        const uint32_t slab = (S << D.sb) + threadIdx.x;
+        const uint32_t v = table2[((size_t)S * D.parts + blockIdx.x) * nsub + threadIdx.x];
+        base[threadIdx.x] += r0 + ((v && slab < D.nslabs) ? atomicAdd(&slab_cursor[slab], v) : 0u);   // this block's first slot in the slab
+    }
+    __syncthreads();
+    const uint32_t chunk = (r1 - r0 + D.parts - 1) / D.parts;
+    const uint32_t b0 = min(r1, r0 + blockIdx.x * chunk), b1 = min(r1, b0 + chunk);
+    for (uint32_t i = b0 + threadIdx.x; i < b1; i += kGbThreads) {
+        const float4 P = recs[i];
+        tmp[atomicAdd(&base[(gb_cell(G, P.x, P.y, P.z) >> D.s1) - (S << D.sb)], 1u)] = P;
+    }
+}
+
 // level 2: block b owns slab b = cells [b << s1, min(ncells, (b + 1) << s1)) = records tmp[slab_start[b], slab_start[b + 1]).
 // A slab of at most stage_cap records (the normal case: the host sizes the slabs for ~1-6 k points) is read ONCE into registers,
 // ranked through the LDS cell counters, placed in LDS at its sorted position and written out as one contiguous run -- whole

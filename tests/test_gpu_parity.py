@@ -731,11 +731,15 @@ def _check_cell_index(c, pts):
     assert np.all(cs[cell] <= pos) and np.all(pos < cs[cell + 1])
 
 
-@pytest.mark.parametrize("shape", ["uniform_1m", "ragged_n", "clustered", "identical", "two_cells", "fine_cells", "small"])
-def test_cell_index_structure(E, oracle, shape):
+@pytest.mark.parametrize("shape", ["uniform_1m", "ragged_n", "clustered", "identical", "two_cells", "fine_cells", "small",
+                                   "uniform_1m/two_pass", "clustered/two_pass", "ragged_n/two_pass"])
+def test_cell_index_structure(E, oracle, shape, monkeypatch):
     """the two-level LDS counting sort (gridbuild.hpp) and the per-point-atomic build it falls back to for small clouds / very fine
     cells: same structural contract, and NN answers through the index equal the oracle's"""
     cell = 0.0
+    if shape.endswith("/two_pass"):            # level 1 of the build in two passes (used from 4096 slabs upwards): forced on small clouds
+        monkeypatch.setenv("PCT_GB_TWO_PASS_MIN_SLABS", "8")
+        shape = shape[:-len("/two_pass")]
     if shape == "uniform_1m":
         pts = synth.uniform_points(3, 1_000_000, 0, 100)
     elif shape == "ragged_n":
