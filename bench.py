@@ -640,6 +640,19 @@ def main():
                            "brute_force_ms": brute_ms, "pair_evals_per_s": 4096 * 1e6 / (brute_ms * 1e-3),
                            "index_build_ms": build_ms, "indexed_ms": grid_ms, "indexed_queries_per_s": 4096 / (grid_ms * 1e-3)}
 
+    if world == 1 and algo == E.ALGO_GRID and a.stream_probe:
+        # the per-frame index build on the headline cloud (setInput's rebuild, corridor_finder.cpp:93-99): bounding box + two-level LDS
+        # counting sort into cells, points already resident in HBM; wall clock around pct_cloud_build_grid (it ends synchronised)
+        tb = []
+        for _ in range(6):
+            E.sync()
+            t1 = time.perf_counter()
+            sc.cloud.build_grid(a.cell)
+            tb.append(1e3 * (time.perf_counter() - t1))
+        bm = float(np.median(tb[1:]))
+        out["index_build_probe"] = {"what": f"pct_cloud_build_grid on the {len(local_pts)}-point cloud resident in HBM (bbox + gb_hist + gb_scatter + gb_cells)",
+                                    "ms_median": bm, "points_per_s": len(local_pts) / (bm * 1e-3)}
+
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
         # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
