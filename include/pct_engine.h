@@ -52,7 +52,8 @@ enum pct_status {
     PCT_ERR_ALLOC = 3,       /* host or device allocation failed */
     PCT_ERR_HIP = 4,         /* a HIP call failed; see pct_last_error() */
     PCT_ERR_EMPTY = 5,       /* query against an empty cloud (outputs are still filled: idx=PCT_NO_INDEX, d2=+inf) */
-    PCT_ERR_CAPACITY = 6     /* more points than the cloud's capacity */
+    PCT_ERR_CAPACITY = 6,    /* more points than the cloud's capacity */
+    PCT_ERR_INTERNAL = 7     /* a self-check of the library failed (e.g. a built index whose records are not a permutation of the cloud) */
 };
 
 #define PCT_NO_INDEX 0xFFFFFFFFu
@@ -316,6 +317,15 @@ int pct_debug_read_bounds(pct_cloud *c, float *out, int64_t Q);
 /* test hook: copies of the cell index as built -- cell_start[ncells + 1] and the cell-ordered records (4 floats per point:
  * x, y, z, bit-cast original index); either pointer may be NULL */
 int pct_debug_read_grid(pct_cloud *c, uint32_t *cell_start, float *records);
+/* the same index checked on the device, through the caches the query kernels read it through:
+ * out = {ids out of range, duplicated ids, records outside their cell's run, decreasing cell_start steps, cell_start[0],
+ * cell_start[ncells]} -- a sound index gives {0, 0, 0, 0, 0, n} */
+int pct_debug_verify_grid(pct_cloud *c, uint64_t out[6]);
+/* work counters of the last instrumented batch: {points scanned, cell runs scanned, pyramid node visits (8 boxes of 32 B each)} */
+int pct_last_work_ex(pct_cloud *c, uint64_t out[3]);
+/* bounding-box pyramid over the cell index (built for sparsely occupied clouds; PCT_PYRAMID=0/1 never / always):
+ * levels = 0 when the cloud has none; empty_fraction = empty cells / cells of the index as built */
+int pct_cloud_pyramid_info(const pct_cloud *c, int32_t *levels, int64_t *nodes, double *empty_fraction);
 
 #ifdef __cplusplus
 }

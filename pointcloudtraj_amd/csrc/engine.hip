@@ -24,6 +24,7 @@
 #include "engine_internal.hpp"
 #include "kernels.hpp"
 #include "gridbuild.hpp"
+#include "pyramid.hpp"
 #include "ring.hpp"
 #include "brute2.hpp"
 
@@ -135,6 +136,15 @@ struct pct_cloud {
     double *h_bpos = nullptr, *d_bpos = nullptr;        // express Bezier check: sample positions
     unsigned char *d_stage = nullptr;
     size_t stage_bytes = 0;
+    float *d_bbox = nullptr;                    // bounding-box partials of the index build (a buffer of their own, not the upload staging)
+    GbCheck *d_gbcheck = nullptr, *h_gbcheck = nullptr;     // the build's self-check (gridbuild.hpp): device words + pinned read-back
+    GbCheck last_check{};                       // as read back by the last build
+    // bounding-box pyramid over the cell index (pyramid.hpp): built for clouds with sparse occupancy
+    bool has_pyr = false;
+    PyrDesc P{};
+    PyrNode *pyr_nodes = nullptr;
+    size_t pyr_cap = 0, pyr_total = 0;
+    double empty_frac = 0.0;
     // grid
     bool has_grid = false;
     GridDesc G{};
@@ -331,6 +341,25 @@ int ensure_stage(pct_cloud *c, size_t bytes)
     return PCT_OK;
 }
 
+// Close a build: read the self-check back behind the last launch, synchronise, compare.  The ids of the records must sum and xor
+// to those of 0..n-1 and no record may sit outside its slab / cell; anything else is a wrong index and is reported, not served.
+int finish_build(pct_cloud *c, const GridDesc &G, hipError_t e, hipStream_t s)
+{
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_gbcheck, c->d_gbcheck, sizeof(GbCheck), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
+    const GbCheck k = *c->h_gbcheck;
+    c->last_check = k;
+    const uint64_t n = (uint64_t)c->count;
+    const uint64_t want_sum = n * (n - 1) / 2;
+    uint32_t want_xor = 0;                       // xor of 0 .. n-1
+    switch ((n - 1) & 3u) { case 0: want_xor = (uint32_t)(n - 1); break; case 1: want_xor = 1u; break; case 2: want_xor = (uint32_t)n; break; default: want_xor = 0u; }
+    if (k.sum_ids != want_sum || k.xor_ids != want_xor || k.misplaced != 0 || k.empty_cells > G.ncells)
+        return fail(PCT_ERR_INTERNAL, "index build self-check failed: ids sum %llu (want %llu) xor %08x (want %08x), %u misplaced records, %u of %u cells empty",
+                    (unsigned long long)k.sum_ids, (unsigned long long)want_sum, k.xor_ids, want_xor, k.misplaced, k.empty_cells, G.ncells);
+    return PCT_OK;
+}
+
 // counting sort of the cloud into the cells of G: cell_start (ncells+1 prefix) and the float4 {x,y,z,index} copy in cell order
 int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size_t *cells_cap, float4 **sorted, size_t *sorted_cap)
 {
@@ -422,38 +451,36 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
             uint32_t *tableA = c->gb_small, *super_total = tableA + (size_t)blocks * DA.nslabs, *super_cursor = super_total + DA.nslabs,
                      *super_start = super_cursor + DA.nslabs, *table2 = super_start + DA.nslabs + 1,
                      *slab_total = table2 + (size_t)DB.nsuper * DB.parts * nsub, *slab_cursor = slab_total + D.nslabs, *slab_start = slab_cursor + D.nslabs;
-            hipError_t e = hipMemsetAsync(super_total, 0, sizeof(uint32_t) * 2 * DA.nslabs, s);
-            if (e == hipSuccess) e = hipMemsetAsync(slab_total, 0, sizeof(uint32_t) * 2 * D.nslabs, s);
-            if (e == hipSuccess) {
+            hipError_t e = hipSuccess;
+            gb_zero_kernel<<<ceil_div(2 * (int64_t)DA.nslabs, 256), 256, 0, s>>>(super_total, 2 * DA.nslabs, nullptr);
+            gb_zero_kernel<<<ceil_div(2 * (int64_t)D.nslabs, 256), 256, 0, s>>>(slab_total, 2 * D.nslabs, c->d_gbcheck);
+            {
                 const size_t ldsA = sizeof(uint32_t) * ((size_t)DA.nslabs + 1);
                 gb_hist_kernel<<<blocks, kGbThreads, ldsA, s>>>(G, DA, c->x, c->y, c->z, (uint32_t)n, tableA, super_total);
                 gb_scatter_kernel<<<blocks, kGbThreads, ldsA, s>>>(G, DA, c->x, c->y, c->z, (uint32_t)n, tableA, super_total, super_cursor, super_start, *sorted);
                 const dim3 g2(DB.parts, DB.nsuper);
                 gb_hist2_kernel<<<g2, kGbThreads, 0, s>>>(G, DB, super_start, *sorted, table2, slab_total);
                 gb_scatter2_kernel<<<g2, kGbThreads, 0, s>>>(G, DB, super_start, *sorted, table2, slab_total, slab_cursor, slab_start, (uint32_t)n, c->gb_tmp);
-                if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
-                else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
-                else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+                if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
+                else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
+                else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipStreamSynchronize(s);
-            if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
-            return PCT_OK;
+            return finish_build(c, G, e, s);
         }
         uint32_t *table = c->gb_small, *slab_total = table + (size_t)blocks * D.nslabs, *slab_cursor = slab_total + D.nslabs,
                  *slab_start = slab_cursor + D.nslabs;
-        hipError_t e = hipMemsetAsync(slab_total, 0, sizeof(uint32_t) * 2 * D.nslabs, s);
-        if (e == hipSuccess) {
+        hipError_t e = hipSuccess;
+        gb_zero_kernel<<<ceil_div(2 * (int64_t)D.nslabs, 256), 256, 0, s>>>(slab_total, 2 * D.nslabs, c->d_gbcheck);
+        {
             gb_hist_kernel<<<blocks, kGbThreads, lds1, s>>>(G, D, c->x, c->y, c->z, (uint32_t)n, table, slab_total);
             gb_scatter_kernel<<<blocks, kGbThreads, lds1, s>>>(G, D, c->x, c->y, c->z, (uint32_t)n, table, slab_total, slab_cursor, slab_start, c->gb_tmp);
-            if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
-            else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
-            else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted);
+            if (cthreads == 256) gb_cells_kernel<256><<<(int)D.nslabs, 256, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
+            else if (cthreads == 512) gb_cells_kernel<512><<<(int)D.nslabs, 512, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
+            else gb_cells_kernel<1024><<<(int)D.nslabs, 1024, lds2, s>>>(G, D, slab_start, c->gb_tmp, (uint32_t)n, stage_cap, *cell_start, *sorted, c->d_gbcheck);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
-        return PCT_OK;
+        return finish_build(c, G, e, s);
     }
     // ---- small clouds / very fine user-given cells: one device atomic per point and pass ----
     uint32_t *d_cnt = nullptr, *d_pcell = nullptr, *d_tiles = nullptr;
@@ -473,18 +500,65 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
     }
     if (e == hipSuccess) {
         cell_scatter_kernel<<<pblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_pcell, *cell_start, d_cnt, *sorted);
+        gb_zero_kernel<<<1, 64, 0, s>>>(nullptr, 0, c->d_gbcheck);
+        gb_check_kernel<<<(int)std::min<int64_t>(1024, (std::max<int64_t>(n, (int64_t)ncells) + 255) / 256), 256, 0, s>>>(G, *sorted, *cell_start, (uint32_t)n, c->d_gbcheck);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    st = finish_build(c, G, e, s);
     dev_free(d_cnt); dev_free(d_pcell); dev_free(d_tiles);
-    if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
-    return PCT_OK;
+    return st;
 }
 
 void drop_grid(pct_cloud *c)
 {
     if (c->has_grid) c->generation++;
     c->has_grid = false;
+    c->has_pyr = false;
+}
+
+// Bounding-box pyramid over the freshly built cell index (pyramid.hpp).  Built when the index is sparsely occupied -- surfaces,
+// clusters, a window much larger than its contents: the clouds on which the shell walk pays for empty space -- or on request
+// (PCT_PYRAMID=1 forces it on any cloud: the tests and the soak run the dense fixtures through the walk that way; =0 never).
+int build_pyramid(pct_cloud *c, const GridDesc &G)
+{
+    c->has_pyr = false;
+    c->empty_frac = G.ncells ? (double)c->last_check.empty_cells / (double)G.ncells : 0.0;
+    int mode = -1;
+    if (const char *e = std::getenv("PCT_PYRAMID")) mode = std::atoi(e);
+    double min_empty = 0.25;                      // uniform cloud at 6 points per cell: e^-6 = 0.25 % of the cells are empty
+    if (const char *e = std::getenv("PCT_PYRAMID_MIN_EMPTY")) min_empty = std::atof(e);
+    if (mode == 0 || (mode < 0 && c->empty_frac < min_empty)) return PCT_OK;
+    PyrDesc P{};
+    size_t total = 0;
+    int l = 0;
+    for (;; l++) {
+        if (l >= kPyrMaxLevels) return fail(PCT_ERR_INTERNAL, "pyramid deeper than %d levels", kPyrMaxLevels);
+        const int gx = pyr_dim(G.gx, l), gy = pyr_dim(G.gy, l), gz = pyr_dim(G.gz, l);
+        P.off[l] = (uint32_t)total;
+        total += (size_t)gx * gy * gz;
+        if (gx <= 2 && gy <= 2 && gz <= 2) break;
+    }
+    P.nlev = l + 1;
+    if (total > 0xFFFFFFF0ull) return PCT_OK;      // cannot be addressed with 32-bit node offsets: stay with the shell walk
+    if (total > c->pyr_cap) {
+        dev_free(c->pyr_nodes);
+        c->pyr_cap = 0;
+        PCTCHK(dev_alloc(&c->pyr_nodes, total));
+        c->pyr_cap = total;
+    }
+    hipStream_t s = g_stream;
+    pyr_leaf_kernel<<<ceil_div((int64_t)G.ncells, 32), 256, 0, s>>>(G, c->sorted, c->cell_start, c->pyr_nodes, nullptr);
+    for (int k = 1; k < P.nlev; k++) {
+        const int gx = pyr_dim(G.gx, k), gy = pyr_dim(G.gy, k), gz = pyr_dim(G.gz, k);
+        pyr_up_kernel<<<ceil_div((int64_t)gx * gy * gz, 256), 256, 0, s>>>(gx, gy, gz, pyr_dim(G.gx, k - 1), pyr_dim(G.gy, k - 1), pyr_dim(G.gz, k - 1),
+                                                                            c->pyr_nodes + P.off[k - 1], c->pyr_nodes + P.off[k]);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    c->P = P;
+    c->pyr_total = total;
+    c->has_pyr = true;
+    return PCT_OK;
 }
 
 // host AoS -> device SoA slots [dst0, dst0+n)
@@ -734,8 +808,7 @@ int cloud_bbox_cached(pct_cloud *c)
     hipStream_t s = g_stream;
     const int64_t n = c->count;
     const int bblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
-    PCTCHK(ensure_stage(c, sizeof(float) * (size_t)bblocks * 6));     // the upload staging buffer is idle here: no allocation per build
-    float *d_part = reinterpret_cast<float *>(c->d_stage);
+    float *d_part = c->d_bbox;                                         // 1024 x 6 floats, allocated with the cloud
     bbox_partial_kernel<<<bblocks, 256, 0, s>>>(c->x, c->y, c->z, (uint32_t)n, d_part);
     std::vector<float> part((size_t)bblocks * 6);
     hipError_t e = hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s);
@@ -958,7 +1031,16 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
             // wave-cooperative fallback for the queries the 2x2x2 block leaves undecided (kernels.hpp, default) or the 8-lane cube
             static const bool wave_cube = [] { const char *e = std::getenv("PCT_COOP_WAVE_CUBE"); return e ? std::atoi(e) != 0 : true; }();
             const float4 *recs = perm ? c->d_qsorted : nullptr;
-            if (c->count_work) {
+            if (c->has_pyr) {     // sparse occupancy: stage 0, then the bounding-box pyramid instead of cube + shells (pyramid.hpp)
+                if (c->count_work)
+                    nn_grid_pyr_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                else if (c->dom_valid && dom_ext_on()) {
+                    hipExtLaunchKernelGGL((nn_grid_pyr_kernel<false>), dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q,
+                                          (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                    dom_done(c);
+                } else
+                    nn_grid_pyr_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+            } else if (c->count_work) {
                 if (wave_cube) nn_grid_coop_kernel<true, true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
                 else nn_grid_coop_kernel<true, false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
             } else if (c->dom_valid && dom_ext_on()) {
@@ -1175,6 +1257,9 @@ static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out
     else
         s = dev_alloc(&c->x, (size_t)c->cap4 + 4) || dev_alloc(&c->y, (size_t)c->cap4 + 4) || dev_alloc(&c->z, (size_t)c->cap4 + 4);
     if (!s) s = dev_alloc(&c->d_work, kWorkSlots);
+    if (!s) s = dev_alloc(&c->d_bbox, (size_t)1024 * 6);
+    if (!s) s = dev_alloc(&c->d_gbcheck, 1);
+    if (!s && hipHostMalloc((void **)&c->h_gbcheck, sizeof(GbCheck), hipHostMallocDefault) != hipSuccess) s = fail(PCT_ERR_ALLOC, "hipHostMalloc failed");
     if (!s) s = mapped_alloc(&c->h_xout, &c->d_xout, kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xin, &c->d_xin, 3 * kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xr, &c->d_xr, kExpressMaxQ);
@@ -1241,6 +1326,8 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
+    dev_free(c->d_bbox); dev_free(c->d_gbcheck); dev_free(c->pyr_nodes);
+    if (c->h_gbcheck) (void)hipHostFree(c->h_gbcheck);
     dev_free(c->ring_ht); dev_free(c->ring_slots); dev_free(c->ring_ovf); dev_free(c->ring_where); dev_free(c->ring_st);
     if (c->h_ring_status) (void)hipHostFree(c->h_ring_status);
     replan_ctx_free(c->rp);
@@ -1457,6 +1544,7 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
 
     // 3. counting sort
     PCTCHK(sort_into_cells(c, G, &c->cell_start, &c->cells_cap, &c->sorted, &c->sorted_cap));
+    PCTCHK(build_pyramid(c, G));
     // 4. sparse occupancy (points on surfaces): add coarser levels so free-space queries do not walk empty fine shells
     c->C.n = 0;
     {
@@ -2297,6 +2385,55 @@ int pct_last_work(pct_cloud *c, uint64_t *points_scanned, uint64_t *cells_scanne
     }
     if (points_scanned) *points_scanned = w.points;
     if (cells_scanned) *cells_scanned = w.cells;
+    return PCT_OK;
+}
+
+int pct_last_work_ex(pct_cloud *c, uint64_t out[3])
+{
+    if (!c || !out) return fail(PCT_ERR_INVALID, "bad arguments");
+    out[0] = out[1] = out[2] = 0;
+    if (c->host_work) { out[0] = c->host_points; return PCT_OK; }
+    WorkCounters slots[kWorkSlots];
+    HIPCHK(hipStreamSynchronize(g_stream));
+    HIPCHK(hipMemcpy(slots, c->d_work, sizeof slots, hipMemcpyDeviceToHost));
+    for (const WorkCounters &k : slots) { out[0] += k.points; out[1] += k.cells; out[2] += k.nodes; }
+    return PCT_OK;
+}
+
+int pct_cloud_pyramid_info(const pct_cloud *c, int32_t *levels, int64_t *nodes, double *empty_fraction)
+{
+    if (!c || !c->has_grid) return fail(PCT_ERR_INVALID, "no cell index");
+    if (levels) *levels = c->has_pyr ? c->P.nlev : 0;
+    if (nodes) *nodes = c->has_pyr ? (int64_t)c->pyr_total : 0;
+    if (empty_fraction) *empty_fraction = c->empty_frac;
+    return PCT_OK;
+}
+
+int pct_debug_verify_grid(pct_cloud *c, uint64_t out[6])
+{
+    if (!c || !c->has_grid || !out) return fail(PCT_ERR_INVALID, "no cell index");
+    const uint32_t n = (uint32_t)c->count;
+    uint32_t *bitmap = nullptr;
+    unsigned long long *d_out = nullptr;
+    const size_t words = ((size_t)n + 31) / 32;
+    int st = dev_alloc(&bitmap, words);
+    if (!st) st = dev_alloc(&d_out, 6);
+    hipError_t e = hipSuccess;
+    if (!st) {
+        e = hipMemsetAsync(bitmap, 0, sizeof(uint32_t) * std::max<size_t>(words, 1), g_stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * 6, g_stream);
+        if (e == hipSuccess) {
+            grid_verify_kernel<<<(int)std::min<int64_t>(2048, (std::max<int64_t>(n, (int64_t)c->G.ncells) + 255) / 256), 256, 0, g_stream>>>(c->G, c->sorted, c->cell_start, n, bitmap, d_out);
+            e = hipGetLastError();
+        }
+        unsigned long long h[6] = { 0, 0, 0, 0, 0, 0 };
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, g_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+        for (int k = 0; k < 6; k++) out[k] = h[k];
+    }
+    dev_free(bitmap); dev_free(d_out);
+    if (st) return st;
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "verify_grid: %s", hipGetErrorString(e));
     return PCT_OK;
 }
 

@@ -28,9 +28,103 @@ struct GbDesc {
     uint32_t chunk;        // points per block of level 1 (multiple of 4)
 };
 
+// Self-check of a build, accumulated by the kernels that write the index (no extra pass) and compared on the host at the build's
+// closing synchronise: the record ids must be a permutation of 0..n-1 (sum and xor of the ids are necessary conditions that a
+// duplicated / lost / stale record breaks), no record may sit outside its slab, and the number of empty cells comes for free.
+// A mismatch makes pct_cloud_build_grid FAIL (PCT_ERR_INTERNAL) instead of handing out an index that answers wrongly.
+struct GbCheck { unsigned long long sum_ids; uint32_t xor_ids, misplaced, empty_cells, pad; };
+
+// zeroes the build's counters (a kernel of this library on the build's stream, not a runtime memset: one thing less between the
+// launches that is not ours)
+__global__ __launch_bounds__(256) void gb_zero_kernel(uint32_t *__restrict__ a, uint32_t n, GbCheck *__restrict__ chk)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = 0u;
+    if (i == 0 && chk) { chk->sum_ids = 0ull; chk->xor_ids = 0u; chk->misplaced = 0u; chk->empty_cells = 0u; chk->pad = 0u; }
+}
+
+// fold a thread's share of the check over the block (LDS), one set of global atomics per block
+__device__ __forceinline__ void gb_check_commit(unsigned long long sum, uint32_t xr, uint32_t bad, uint32_t empty, GbCheck *__restrict__ chk)
+{
+    __shared__ unsigned long long s_sum;
+    __shared__ uint32_t s_xor, s_bad, s_empty;
+    if (threadIdx.x == 0) { s_sum = 0ull; s_xor = 0u; s_bad = 0u; s_empty = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += (unsigned long long)__shfl_xor((long long)sum, off, kWave);
+        xr ^= (uint32_t)__shfl_xor((int)xr, off, kWave);
+        bad += (uint32_t)__shfl_xor((int)bad, off, kWave);
+        empty += (uint32_t)__shfl_xor((int)empty, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_sum, sum); atomicXor(&s_xor, xr);
+        if (bad) atomicAdd(&s_bad, bad);
+        if (empty) atomicAdd(&s_empty, empty);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&chk->sum_ids, s_sum); atomicXor(&chk->xor_ids, s_xor);
+        if (s_bad) atomicAdd(&chk->misplaced, s_bad);
+        if (s_empty) atomicAdd(&chk->empty_cells, s_empty);
+    }
+}
+
+// the same check over a finished index by a pass of its own (the per-point-atomic build of small clouds / very fine cells)
+__global__ __launch_bounds__(256) void gb_check_kernel(GridDesc G, const float4 *__restrict__ sorted, const uint32_t *__restrict__ cell_start,
+                                                       uint32_t n, GbCheck *__restrict__ chk);
+
 __device__ __forceinline__ uint32_t gb_cell(const GridDesc &G, float px, float py, float pz)
 {
     return cell_lin(G, cell_coord(px, G.ox, G.inv_h, G.gx), cell_coord(py, G.oy, G.inv_h, G.gy), cell_coord(pz, G.oz, G.inv_h, G.gz));
+}
+
+__global__ __launch_bounds__(256) void gb_check_kernel(GridDesc G, const float4 *__restrict__ sorted, const uint32_t *__restrict__ cell_start,
+                                                       uint32_t n, GbCheck *__restrict__ chk)
+{
+    unsigned long long sum = 0;
+    uint32_t xr = 0, bad = 0, empty = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const float4 P = sorted[p];
+        const uint32_t id = __float_as_uint(P.w), cell = gb_cell(G, P.x, P.y, P.z);
+        sum += id; xr ^= id;
+        bad += (cell_start[cell] <= p && p < cell_start[cell + 1]) ? 0u : 1u;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G.ncells; i += stride) empty += cell_start[i + 1] == cell_start[i] ? 1u : 0u;
+    gb_check_commit(sum, xr, bad, empty, chk);
+}
+
+// Full structural verification of a built index AS THE KERNELS SEE IT (through the caches, on the stream that serves the queries):
+// every id below n and seen exactly once (bitmap), every record inside the run of the cell its coordinates map to, cell_start a
+// non-decreasing prefix from 0 to n.  out = {ids out of range, duplicated ids, misplaced records, decreasing cell_start steps,
+// cell_start[0], cell_start[ncells]}.  Test hook (pct_debug_verify_grid): when a host read-back of the index and this disagree,
+// the fault is in the read-back path, not in the index.
+__global__ __launch_bounds__(256) void grid_verify_kernel(GridDesc G, const float4 *__restrict__ sorted, const uint32_t *__restrict__ cell_start,
+                                                          uint32_t n, uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ out)
+{
+    uint32_t bad_id = 0, dup = 0, misplaced = 0, decreasing = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const float4 P = sorted[p];
+        const uint32_t id = __float_as_uint(P.w), cell = gb_cell(G, P.x, P.y, P.z);
+        if (id >= n) bad_id++;
+        else if (atomicOr(&bitmap[id >> 5], 1u << (id & 31u)) & (1u << (id & 31u))) dup++;
+        misplaced += (cell_start[cell] <= p && p < cell_start[cell + 1]) ? 0u : 1u;
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G.ncells; i += stride) decreasing += cell_start[i + 1] < cell_start[i] ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad_id += (uint32_t)__shfl_xor((int)bad_id, off, kWave); dup += (uint32_t)__shfl_xor((int)dup, off, kWave);
+        misplaced += (uint32_t)__shfl_xor((int)misplaced, off, kWave); decreasing += (uint32_t)__shfl_xor((int)decreasing, off, kWave);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad_id) atomicAdd(&out[0], (unsigned long long)bad_id);
+        if (dup) atomicAdd(&out[1], (unsigned long long)dup);
+        if (misplaced) atomicAdd(&out[2], (unsigned long long)misplaced);
+        if (decreasing) atomicAdd(&out[3], (unsigned long long)decreasing);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[4] = cell_start[0]; out[5] = cell_start[G.ncells]; }
 }
 
 // level 1, pass A: table[block][slab] = points of the block's chunk in the slab; slab_total[slab] += the same
@@ -208,8 +302,11 @@ constexpr int kGbStagePerThread = 8;                                 // stage_ca
 template <int kGbCellThreads>
 __global__ __launch_bounds__(kGbCellThreads) void gb_cells_kernel(GridDesc G, GbDesc D, const uint32_t *__restrict__ slab_start,
                                                                   const float4 *__restrict__ tmp, uint32_t n, uint32_t stage_cap,
-                                                                  uint32_t *__restrict__ cell_start, float4 *__restrict__ sorted)
+                                                                  uint32_t *__restrict__ cell_start, float4 *__restrict__ sorted,
+                                                                  GbCheck *__restrict__ chk)
 {
+    unsigned long long k_sum = 0;                                    // self-check (GbCheck), accumulated from the records in hand
+    uint32_t k_xor = 0, k_bad = 0, k_empty = 0;
     extern __shared__ uint32_t cnt[];
     __shared__ uint32_t s_wave[kGbCellThreads / 64], s_carry;
     float4 *stage = reinterpret_cast<float4 *>(cnt + ((((1u << D.s1) + 1) + 3) & ~3u));
@@ -227,12 +324,18 @@ __global__ __launch_bounds__(kGbCellThreads) void gb_cells_kernel(GridDesc G, Gb
             if (i < np) {
                 R[k] = tmp[p0 + i];
                 cell[k] = gb_cell(G, R[k].x, R[k].y, R[k].z) - c0;
+                const uint32_t id = __float_as_uint(R[k].w);
+                k_sum += id; k_xor ^= id;
+                if (cell[k] >= m) { k_bad++; cell[k] = 0; }               // a record that is not this slab's (cannot happen): counted, kept in range
                 atomicAdd(&cnt[cell[k]], 1u);
             }
         }
         __syncthreads();
         gb_block_scan<kGbCellThreads>(cnt, m, s_wave, &s_carry);
-        for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) cell_start[c0 + i] = p0 + cnt[i];
+        for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) {
+            cell_start[c0 + i] = p0 + cnt[i];
+            k_empty += cnt[i + 1] == cnt[i] ? 1u : 0u;
+        }
         if (c1 == G.ncells && threadIdx.x == 0) cell_start[G.ncells] = n;
         __syncthreads();
 #pragma unroll
@@ -242,21 +345,32 @@ __global__ __launch_bounds__(kGbCellThreads) void gb_cells_kernel(GridDesc G, Gb
         }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < np; i += kGbCellThreads) sorted[p0 + i] = stage[i];
+        gb_check_commit(k_sum, k_xor, k_bad, k_empty, chk);
         return;
     }
     for (uint32_t i = p0 + threadIdx.x; i < p1; i += kGbCellThreads) {
         const float4 P = tmp[i];
-        atomicAdd(&cnt[gb_cell(G, P.x, P.y, P.z) - c0], 1u);
+        uint32_t cl = gb_cell(G, P.x, P.y, P.z) - c0;
+        const uint32_t id = __float_as_uint(P.w);
+        k_sum += id; k_xor ^= id;
+        if (cl >= m) { k_bad++; cl = 0; }
+        atomicAdd(&cnt[cl], 1u);
     }
     __syncthreads();
     gb_block_scan<kGbCellThreads>(cnt, m, s_wave, &s_carry);
-    for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) cell_start[c0 + i] = p0 + cnt[i];
+    for (uint32_t i = threadIdx.x; i < m; i += kGbCellThreads) {
+        cell_start[c0 + i] = p0 + cnt[i];
+        k_empty += cnt[i + 1] == cnt[i] ? 1u : 0u;
+    }
     if (c1 == G.ncells && threadIdx.x == 0) cell_start[G.ncells] = n;
     __syncthreads();
     for (uint32_t i = p0 + threadIdx.x; i < p1; i += kGbCellThreads) {
         const float4 P = tmp[i];
-        sorted[p0 + atomicAdd(&cnt[gb_cell(G, P.x, P.y, P.z) - c0], 1u)] = P;
+        uint32_t cl = gb_cell(G, P.x, P.y, P.z) - c0;
+        if (cl >= m) cl = 0;
+        sorted[p0 + atomicAdd(&cnt[cl], 1u)] = P;
     }
+    gb_check_commit(k_sum, k_xor, k_bad, k_empty, chk);
 }
 
 }  // namespace pct

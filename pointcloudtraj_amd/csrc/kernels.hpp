@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(256) void unpermute_results_kernel(const uint32_t *
 //    `bound` away (distance to the cube's faces, minus a slack covering the fp32 cell
 //    assignment rounding), so the search stops once best_d2 <= bound^2.
 // =====================================================================================
-struct WorkCounters { unsigned long long points, cells; };
+struct WorkCounters { unsigned long long points, cells, nodes; };    // nodes: pyramid node visits (pyramid.hpp), 8 boxes of 32 bytes each
 constexpr int kWorkSlots = 64;    // instrumented kernels spread their two counters over 64 slots (same-address atomics serialise)
 
 // XCD-aware block order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin over

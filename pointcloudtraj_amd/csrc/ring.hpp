@@ -76,6 +76,7 @@ __device__ __forceinline__ uint32_t ring_bucket_of(const RingDesc &R, float x, f
 // inside its bucket.  Eviction goes straight to the record (no search) and marks it dead; heads then advance past dead records.
 constexpr uint32_t kRingInOvf = 0x80000000u;
 constexpr uint32_t kRingDead = 0xFFFFFFFFu;      // a record's id word once its point has left the window
+constexpr uint32_t kRingUnfiled = 0xFFFFFFFFu;   // where[] of a point the overflow queue had no room for (an error state the host repairs)
 
 // file one point under its bucket (or the overflow queue when the bucket is full); heads do not move while this runs
 __device__ __forceinline__ void ring_file(const RingDesc &R, float px, float py, float pz, uint32_t slot, uint2 *__restrict__ ht,
@@ -97,8 +98,14 @@ __device__ __forceinline__ void ring_file(const RingDesc &R, float px, float py,
         t = seen;
     }
     const uint32_t pos = atomicAdd(&st->ovf_tail, 1u);
-    if (pos - __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > R.ovf_mask)
-        __hip_atomic_store(&R.status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // cannot happen (see RingDesc); if it does the host rebuilds
+    if (pos - __hip_atomic_load(&st->ovf_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > R.ovf_mask) {
+        // cannot happen (see RingDesc).  If it does: no live record is clobbered -- the point stays reachable from the SoA arrays
+        // only, marked unfiled so that its eviction touches nothing, and the status word makes the host refile the whole window
+        // before the next answer is handed out (ring_host.inc: ring_overrun_repair)
+        __hip_atomic_store(&R.status[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        where[slot] = kRingUnfiled;
+        return;
+    }
     ovf[pos & R.ovf_mask] = rec;
     where[slot] = (pos & ~kRingInOvf) | kRingInOvf;
 }
@@ -119,7 +126,9 @@ __global__ __launch_bounds__(256) void ring_evict_kernel(RingDesc R, const float
     if (i < n) {
         const uint32_t slot = slot0 + i;
         const uint32_t w = where[slot];
-        if (w & kRingInOvf) {
+        if (w == kRingUnfiled) {
+            // never filed (queue overrun): nothing to retire
+        } else if (w & kRingInOvf) {
             uint32_t *idw = reinterpret_cast<uint32_t *>(&ovf[w & R.ovf_mask].w);
             __hip_atomic_store(idw, kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -339,7 +348,13 @@ struct ReplanHeader {
 
 struct ReplanSummary { long long first_hit_sample, first_hit_ctrl; int32_t n_nodes, n_samples, n_ctrl; uint32_t seq; };
 // device words the blocks of one batch meet on: a ticket counter and the running first-hit minima (reset by the last block)
-struct ReplanMeet { uint32_t ticket; int32_t first_sample, first_ctrl; uint32_t pad; };
+// `launches` counts the launches that have drained COMPLETELY (every block of the captured grid, participating or not): launch
+// number L (1-based) reads header slot L & 1, and the host writes tick L's header into that slot.  The host is released by the last
+// PARTICIPATING block, so it may fill tick L+1's header (the other slot) while trailing blocks of launch L are still starting; slot
+// L & 1 is not written again before tick L+2, whose fill comes after tick L+1's answer, i.e. after launch L has drained (stream
+// order).  A launch's header is therefore immutable while the launch is alive.
+struct ReplanMeet { uint32_t ticket; int32_t first_sample, first_ctrl; uint32_t launches; uint32_t done; uint32_t pad[3]; };
+constexpr size_t kReplanHdrSlot = 256;          // bytes per header slot in the argument block
 
 template <bool RING>
 __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc G0, const float4 *__restrict__ pts0,
@@ -353,10 +368,24 @@ __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc 
     __shared__ uint32_t s_i[4];
     __shared__ double s_term[3 * (kMaxBezierOrder + 1)];
     __shared__ double s_pos[3];
-    const ReplanHeader H = *hdr;
+    __shared__ ReplanHeader s_H;
+    // ONE thread fetches the header (host-mapped memory by default: a bus read) -- the slot of this launch's parity, see ReplanMeet
+    if (threadIdx.x == 0) {
+        const uint32_t launch = __hip_atomic_load(&meet->launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s_H = *reinterpret_cast<const ReplanHeader *>(reinterpret_cast<const unsigned char *>(hdr) + (launch & 1u) * kReplanHdrSlot);
+    }
+    __syncthreads();
+    const ReplanHeader H = s_H;
     const int slot = (int)blockIdx.x;
     const int total = H.n_nodes + H.n_samples + H.n_ctrl;
-    if (slot >= total) return;
+    // every block of the grid, trailing ones included, signs off; the last one closes the launch (next launch = other header slot)
+    auto sign_off = [&]() {
+        if (threadIdx.x == 0 && atomicAdd(&meet->done, 1u) == gridDim.x - 1u) {
+            atomicExch(&meet->done, 0u);
+            atomicAdd(&meet->launches, 1u);
+        }
+    };
+    if (slot >= total) { sign_off(); return; }
     const InflateParams P = H.P;
     double px, py, pz;
     if (slot < H.n_nodes) {
@@ -427,11 +456,15 @@ __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc 
             __hip_atomic_store(&sum->seq, H.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    sign_off();
 }
 
-// a batch with no planner point at all still has to answer: summary only (one thread; returns at once otherwise)
-__global__ void replan_empty_kernel(const ReplanHeader *__restrict__ hdr, ReplanSummary *__restrict__ sum)
+// a batch with no planner point at all still has to answer: summary only (one thread; returns at once otherwise).  It runs behind
+// the block kernel on the stream, whose last block has already counted the launch: the header slot is the count's own parity.
+__global__ void replan_empty_kernel(const ReplanHeader *__restrict__ hdr, const ReplanMeet *__restrict__ meet, ReplanSummary *__restrict__ sum)
 {
+    const uint32_t launch = __hip_atomic_load(&meet->launches, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hdr = reinterpret_cast<const ReplanHeader *>(reinterpret_cast<const unsigned char *>(hdr) + (launch & 1u) * kReplanHdrSlot);
     if (hdr->n_nodes + hdr->n_samples + hdr->n_ctrl != 0) return;
     sum->first_hit_sample = -1; sum->first_hit_ctrl = -1;
     sum->n_nodes = 0; sum->n_samples = 0; sum->n_ctrl = 0;

@@ -125,6 +125,9 @@ def lib():
         L.pct_merge_mask_dev.argtypes = [vp, vp, vp, vp, i64, vp]
         L.pct_last_work.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_set_work_counters.argtypes = [vp, i32]
+        L.pct_last_work_ex.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.pct_debug_verify_grid.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.pct_cloud_pyramid_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(i64), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -414,6 +417,24 @@ class Cloud:
         a, b = C.c_uint64(), C.c_uint64()
         _chk(lib().pct_last_work(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_work_ex(self):
+        """(points scanned, cell runs scanned, pyramid node visits) of the last instrumented batch"""
+        out = (C.c_uint64 * 3)()
+        _chk(lib().pct_last_work_ex(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def verify_grid(self):
+        """device-side structural check of the built index (pct_debug_verify_grid): dict of fault counts; sound = all zero and
+        cell_start running from 0 to n"""
+        out = (C.c_uint64 * 6)()
+        _chk(lib().pct_debug_verify_grid(self._h, out))
+        return dict(bad_ids=int(out[0]), duplicates=int(out[1]), misplaced=int(out[2]), decreasing=int(out[3]), first=int(out[4]), last=int(out[5]))
+
+    def pyramid_info(self):
+        lv, nodes, ef = C.c_int32(), C.c_int64(), C.c_double()
+        _chk(lib().pct_cloud_pyramid_info(self._h, C.byref(lv), C.byref(nodes), C.byref(ef)))
+        return dict(levels=lv.value, nodes=nodes.value, empty_fraction=ef.value)
 
 
 def _traj(polycoef, seg_time, orders):

@@ -160,6 +160,68 @@ def pillar_map(x_init=-10.0, x_end=9.0, y_init=-10.0, y_end=9.0,
     return np.asarray(pts, dtype=np.float64).astype(np.float32).reshape(-1, 3)
 
 
+def _emplace_np(xa, ya, xb, yb, h_, res):
+    """emplace_rect_to_map (map_generator.cpp:97-125) as index arithmetic: the (x, y, z) lattice indices of one wall / cap, in the
+    reference's loop order"""
+    xa_c, ya_c = int(_cround(xa / res)), int(_cround(ya / res))
+    xb_c, yb_c = int(_cround(xb / res)), int(_cround(yb / res))
+    h_c = int(_cround(h_ / res))
+    xi = 1 if xa_c < xb_c else -1
+    yi = 1 if ya_c < yb_c else -1
+    if xa_c == xb_c:
+        ys = np.arange(ya_c, yb_c, yi, dtype=np.int64)
+        hs = np.arange(1, h_c, dtype=np.int64)
+        Y, H = np.meshgrid(ys, hs, indexing="ij")
+        return np.stack([np.full(Y.size, xa_c, np.int64), Y.ravel(), H.ravel()], 1)
+    if ya_c == yb_c:
+        xs = np.arange(xa_c, xb_c, xi, dtype=np.int64)
+        hs = np.arange(1, h_c, dtype=np.int64)
+        X, H = np.meshgrid(xs, hs, indexing="ij")
+        return np.stack([X.ravel(), np.full(X.size, ya_c, np.int64), H.ravel()], 1)
+    xs = np.arange(xa_c, xb_c + xi, xi, dtype=np.int64)
+    ys = np.arange(ya_c, yb_c + yi, yi, dtype=np.int64)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    return np.stack([X.ravel(), Y.ravel(), np.full(X.size, h_c, np.int64)], 1)
+
+
+def pillar_map_scaled(scale: float = 1.0, seed: int = 6, res: float = 0.1) -> np.ndarray:
+    """The reference's pillar world (map_generator.cpp:16-125 with clean_demo.launch's constants) on a square `scale` times as wide:
+    the same pillar density (120 attempts per 30 m x 30 m), widths, heights and lattice, so the cloud has the reference's surface
+    structure at any size -- scale 1 reproduces pillar_map() point for point (182,332 points); scale 7.5 gives ~10 M points.
+    SURVEY 8(d)'s "clustered variant" of the large configs."""
+    half = 15.0 * scale
+    num = int(round(120 * scale * scale))
+    x_init, y_init, x_end, y_end = -10.0 * scale, -10.0 * scale, 9.0 * scale, 9.0 * scale
+    eng = _MinStd0(seed)
+    cx, cy, cw = np.zeros(num), np.zeros(num), np.zeros(num)
+    k = 0
+    parts = []
+    for _ in range(num):
+        x = eng.uniform(-half, half)
+        y = eng.uniform(-half, half)
+        w = eng.uniform(0.6, 2.0)
+        h = eng.uniform(1.0, 8.0)
+        if ((x - x_init) ** 2 + (y - y_init) ** 2 < 2 + w * w or (x - x_end) ** 2 + (y - y_end) ** 2 < 2 + w * w):
+            continue
+        if k and np.any((cx[:k] - x) ** 2 + (cy[:k] - y) ** 2 < (cw[:k] + w) ** 2):
+            continue
+        cx[k], cy[k], cw[k] = x, y, w
+        k += 1
+        h = _cround(h / res) * res
+        cap = []
+        for phi in (45, 135, 225, 315):
+            xa = _cround((x + w * math.cos(math.pi / 180 * phi)) / res) * res
+            ya = _cround((y + w * math.sin(math.pi / 180 * phi)) / res) * res
+            xb = _cround((x + w * math.cos(math.pi / 180 * (phi + 90))) / res) * res
+            yb = _cround((y + w * math.sin(math.pi / 180 * (phi + 90))) / res) * res
+            cap.append((xa, ya))
+            parts.append(_emplace_np(xa, ya, xb, yb, h, res))
+        parts.append(_emplace_np(cap[0][0], cap[0][1], cap[2][0], cap[2][1], 0, res))
+        parts.append(_emplace_np(cap[0][0], cap[0][1], cap[2][0], cap[2][1], h, res))
+    idx = np.concatenate(parts) if parts else np.zeros((0, 3), np.int64)
+    return (idx.astype(np.float64) * res).astype(np.float32)
+
+
 def crop_ball(points: np.ndarray, center, radius: float) -> np.ndarray:
     d = points.astype(np.float64) - np.asarray(center, dtype=np.float64)
     return points[(d * d).sum(1) <= radius * radius]

@@ -435,12 +435,15 @@ def test_pointcloud2_payload(E, oracle):
     c.close()
 
 
-@pytest.mark.parametrize("pyramid", [False, True])
-def test_sparse_occupancy_clouds(E, oracle, pyramid, monkeypatch):
-    """Clouds whose points sit on surfaces: queries in free space (far from every point) and far outside the box must
-    still return the exact neighbour, through the batch kernel and the express path -- with plain shell expansion
-    (default) and with the optional coarser index levels (PCT_PYRAMID_EMPTY_FRAC)."""
-    if pyramid:
+@pytest.mark.parametrize("mode", ["boxes", "shells", "coarse"])
+def test_sparse_occupancy_clouds(E, oracle, mode, monkeypatch):
+    """Clouds whose points sit on surfaces (the reference's real input, map_generator.cpp:16-125): queries in free space (far from
+    every point) and far outside the box must still return the exact neighbour, through the batch kernel and the express path --
+    with the bounding-box pyramid such clouds get by default (pyramid.hpp; it must also keep the work per query small), with plain
+    shell expansion (PCT_PYRAMID=0) and with the optional coarser index levels of the express kernel (PCT_PYRAMID_EMPTY_FRAC)."""
+    if mode != "boxes":
+        monkeypatch.setenv("PCT_PYRAMID", "0")
+    if mode == "coarse":
         monkeypatch.setenv("PCT_PYRAMID_EMPTY_FRAC", "0.5")
     for pts in (synth.pillar_map(), synth.clustered_points(131, 300000, 0, 60)):
         lo, hi = pts.min(0), pts.max(0)
@@ -448,14 +451,65 @@ def test_sparse_occupancy_clouds(E, oracle, pyramid, monkeypatch):
         q = np.concatenate([(lo + u * (hi - lo)).astype(np.float32), synth.uniform_points(133, 300, -80, 140)])
         bi, bd = oracle.brute_nearest(pts, q)
         c = make_cloud(E, pts, grid=True)
+        assert (c.pyramid_info()["levels"] > 0) == (mode == "boxes"), c.pyramid_info()
         ig, dg = c.nn(q, E.ALGO_GRID)                         # batch kernel (8 lanes per query)
         assert np.array_equal(dg, bd) and np.array_equal(ig.astype(np.int64), bi.astype(np.int64))
+        if mode == "boxes":                                   # the point of the pyramid: free space is not walked cell by cell
+            c.set_work_counters(True)
+            c.nn(q[:30000], E.ALGO_GRID)
+            npts, nruns, nnodes = c.last_work_ex()
+            c.set_work_counters(False)
+            assert npts / 30000 < 400 and nruns / 30000 < 40 and nnodes > 0, (npts / 30000, nruns / 30000, nnodes / 30000)
         ie, de = c.nn(q[:700], E.ALGO_GRID)                   # <= 1024 queries: block-per-query express kernel
         assert np.array_equal(de, bd[:700]) and np.array_equal(ie.astype(np.int64), bi[:700].astype(np.int64))
         prm = E.inflate_params(tuple(float(v) for v in (lo + hi) / 2), 1e9, 0.25, 1.5)
         rad, _, _ = c.inflate(prm, q[:500].astype(np.float64))    # with idx/d2 requested: exact search
         assert np.array_equal(rad, np.minimum(np.sqrt(bd[:500]) - 0.25, 1.5))
         c.close()
+
+
+@pytest.mark.parametrize("shape", ["uniform", "lattice_ties", "duplicates", "identical", "two_cells", "flat", "line", "tiny", "far_origin"])
+def test_box_pyramid_forced_on_every_shape(E, oracle, shape, monkeypatch):
+    """PCT_PYRAMID=1 sends every query the 2x2x2 block leaves undecided through the bounding-box walk whatever the occupancy:
+    dense clouds, exact ties on a lattice (lowest index must win across cells and across subtrees), bulk duplicates, degenerate
+    boxes (flat / collinear / identical points: zero-extent boxes, LB == d2), one- and two-point clouds, coordinates far from the
+    origin -- queries inside, on the points, and far outside.  Bit-exact against the exhaustive oracle."""
+    monkeypatch.setenv("PCT_PYRAMID", "1")
+    if shape == "uniform":
+        pts = synth.uniform_points(201, 150_000, 0, 40)
+    elif shape == "lattice_ties":
+        g = np.arange(0, 24, dtype=np.float32) * np.float32(0.5)
+        pts = np.stack(np.meshgrid(g, g, g[:12], indexing="ij"), -1).reshape(-1, 3)[synth.shuffled_order(202, 24 * 24 * 12)]
+    elif shape == "duplicates":
+        base = synth.uniform_points(203, 3000, -5, 5)
+        pts = base[(synth.splitmix64(204, 90_000) % np.uint64(3000)).astype(np.int64)]
+    elif shape == "identical":
+        pts = np.tile(np.float32([[1.5, -2.0, 0.25]]), (20_000, 1))
+    elif shape == "two_cells":
+        pts = np.concatenate([np.tile(np.float32([[0, 0, 0]]), (9_000, 1)), np.tile(np.float32([[10, 10, 10]]), (9_001, 1))])
+    elif shape == "flat":
+        pts = synth.uniform_points(205, 60_000, 0, 30); pts[:, 2] = np.float32(1.25)
+    elif shape == "line":
+        pts = synth.uniform_points(206, 20_000, 0, 30); pts[:, 1] = np.float32(-3.0); pts[:, 2] = np.float32(7.0)
+    elif shape == "tiny":
+        pts = np.float32([[1, 2, 3], [4, 5, 6]])
+    else:
+        pts = synth.uniform_points(207, 80_000, 0, 50) + np.float32([9.0e4, -1.2e5, 3.0e4])
+    lo, hi = pts.min(0).astype(np.float64), pts.max(0).astype(np.float64)
+    span = np.maximum(hi - lo, 1.0)
+    u = synth.uniform01_f32(208, 3 * 40_000).reshape(-1, 3).astype(np.float64)
+    q = np.concatenate([lo - 0.3 * span + u[:30_000] * 1.6 * span,                      # inside and around the box
+                        lo + (u[30_000:] - 0.5) * 40.0 * span,                           # far outside
+                        pts[:: max(1, len(pts) // 2000)][:2000].astype(np.float64)]).astype(np.float32)
+    if shape == "lattice_ties":                                                          # cell centres / face centres: 2-8 way exact ties
+        q = np.concatenate([q, (np.round(q[:5000] * 4) / 4).astype(np.float32)])
+    c = make_cloud(E, pts, grid=True)
+    assert c.pyramid_info()["levels"] > 0
+    bi, bd = oracle.brute_nearest_mt(pts, q)
+    ig, dg = c.nn(q, E.ALGO_GRID)
+    assert np.array_equal(dg, bd)
+    assert np.array_equal(ig.astype(np.int64), bi.astype(np.int64)), int((ig.astype(np.int64) != bi.astype(np.int64)).sum())
+    c.close()
 
 
 @pytest.mark.gpu
@@ -716,11 +770,24 @@ def _check_cell_index(c, pts):
     """structure of the built index: cell_start is a prefix of the point counts, every record sits in the cell its coordinates
     map to (the fp32 assignment queries use), and the records are a permutation of the cloud"""
     info = c.grid_info()
-    cs, rec = c.debug_read_grid()
     n = len(pts)
+    dev = c.verify_grid()                                   # the index as the query kernels see it (device-side bitmap check)
+    assert dev == dict(bad_ids=0, duplicates=0, misplaced=0, decreasing=0, first=0, last=n), dev
+    cs, rec = c.debug_read_grid()
     assert cs[0] == 0 and cs[-1] == n and np.all(np.diff(cs.astype(np.int64)) >= 0)
     ids = rec[:, 3].copy().view(np.uint32)
-    assert np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    if not np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32)):
+        # evidence for DESIGN.md section 4 ("the non-permutation index of round 2"): what is wrong, where, and whether a second
+        # read-back and the device-side check agree with the first read-back
+        cnt = np.bincount(ids[ids < n], minlength=n)
+        dup, miss = np.nonzero(cnt > 1)[0], np.nonzero(cnt == 0)[0]
+        pos = np.nonzero(np.isin(ids, dup) | (ids >= n))[0]
+        cs2, rec2 = c.debug_read_grid()
+        again = c.verify_grid()
+        raise AssertionError(f"host copy of the index is not a permutation: {len(dup)} duplicated / {len(miss)} missing ids, "
+                             f"{int((ids >= n).sum())} out of range, affected positions {pos[:6]}..{pos[-6:]} "
+                             f"(128-byte lines {np.unique(pos // 8)[:8]}), second read-back identical: {np.array_equal(rec, rec2)}, "
+                             f"device-side check before / after: {dev} / {again}")
     assert np.array_equal(rec[:, :3], pts[ids])
     gx, gy, gz = info["dims"]
     o = np.float32(info["origin"])

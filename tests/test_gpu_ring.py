@@ -461,3 +461,70 @@ def test_device_calls_on_other_streams_follow_asynchronous_mutations(E, oracle):
         wi, wd = oracle.brute_nearest_mt(pts, qh)
         assert np.array_equal(d2.cpu().numpy(), wd) and np.array_equal(idx.cpu().numpy().view(np.uint32).astype(np.int64), wi.astype(np.int64))
     c.close()
+
+
+def test_bezier_check_on_ring_cloud_respects_the_callers_capacity(E, oracle):
+    """pct_bezier_check on a rolling-map cloud runs the fused planner batch on the cloud's own context; its read-out must stop at
+    the caller's `cap` whatever the context holds -- fresh context with cap < samples, and a small cap after a larger context
+    exists (99 samples into arrays of 50 was a heap overflow).  Guard words behind every array must survive; first_hit
+    and the sample count still cover every evaluated sample."""
+    import ctypes as C
+    P = S.C5_PARAMS
+    pts = np.concatenate([S.c5_frame(k, 10_000, 0.0) for k in range(8)])          # no free corridor: the trajectory collides
+    start, nodes, coef, T, od = S.c5_tick_queries(8)
+    prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+    ref = oracle.replan_tick(pts, start, P["sample_range"], P["search_margin"], P["max_radius"], nodes, coef, T, od, 0.0, 2.0, 0.02)
+    assert ref["nsamples"] == 99
+    coefc = np.ascontiguousarray(coef, np.float64); Tc = np.ascontiguousarray(T, np.float64); odc = np.ascontiguousarray(od, np.int32)
+    traj = E.BezierTraj(coefc.ctypes.data_as(C.POINTER(C.c_double)), coefc.shape[1], Tc.ctypes.data_as(C.POINTER(C.c_double)),
+                        odc.ctypes.data_as(C.POINTER(C.c_int32)), len(Tc))
+    GUARD = 64
+
+    def call(c, cap):
+        pos = np.full(3 * cap + GUARD, -7.25, np.float64); rad = np.full(cap + GUARD, -7.25, np.float64)
+        d2 = np.full(cap + GUARD, -7.25, np.float64); idx = np.full(cap + GUARD, 0xABCD1234, np.uint32)
+        fh, ns = C.c_int64(), C.c_int64()
+        E._chk(E.lib().pct_bezier_check(c.handle, C.byref(traj), C.byref(prm), 0.0, 2.0, 0.02, C.byref(fh), C.byref(ns), cap,
+                                        pos.ctypes.data, rad.ctypes.data, d2.ctypes.data, idx.ctypes.data))
+        assert np.all(pos[3 * cap:] == -7.25) and np.all(rad[cap:] == -7.25) and np.all(d2[cap:] == -7.25) and np.all(idx[cap:] == 0xABCD1234), cap
+        assert ns.value == 99, ns.value
+        n = min(cap, 99)
+        same = np.all(pos[:3 * n].reshape(n, 3).astype(np.float32) == ref["sample_pos"][:n].astype(np.float32), axis=1)
+        assert np.array_equal(rad[:n][same], ref["sample_radius"][:n][same])
+        return fh.value
+
+    c = E.Cloud(len(pts)); c.ring_index(); c.set_input(pts)
+    fh_small = call(c, 50)                           # fresh context (128 samples) with cap 50 < 99 samples
+    c.close()
+    c = E.Cloud(len(pts)); c.ring_index(); c.set_input(pts)
+    full = c.bezier_check(prm, coef, T, od, 0.0, 2.0, cap=2048)      # creates a 2048-sample context
+    assert full["n"] == 99
+    fh_after = call(c, 20)                           # small cap, large context already held
+    assert fh_small == fh_after == full["first_hit"]
+    c.close()
+
+
+def test_replan_plan_of_large_capacity_alternating_tick_sizes(E, oracle):
+    """A plan captured for thousands of blocks whose ticks alternate between a handful and thousands of planner points: the trailing
+    blocks of a small tick start while the host is already filling the next, larger tick's arguments (they then read the
+    newer header, joined the next tick's ticket count and released its results one block early).  The header is double-buffered by
+    launch parity now (ring.hpp ReplanMeet); every tick of 120 must equal the oracle's and the un-captured path's."""
+    P = S.C5_PARAMS
+    pts = np.concatenate([S.c5_frame(k, 10_000, 0.6) for k in range(10)])
+    c = E.Cloud(len(pts)); c.ring_index(); c.set_input(pts)
+    plan = E.ReplanPlan(c, 6000, 4000, 4)            # 6000 + 4000 + 4 * 13 blocks per launch
+    rng = np.random.default_rng(5)
+    start, nodes0, coef, T, od = S.c5_tick_queries(10)
+    prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
+    big = (rng.uniform(-1, 1, (6000, 3)) * [8.0, 4.0, 1.5] + [5.0, 0.0, 2.5])
+    want_big, _, _ = oracle.inflate_brute(pts, start, P["sample_range"], P["search_margin"], P["max_radius"], big)
+    for k in range(120):
+        if k % 2 == 0:                                # tiny tick: 3 nodes, no trajectory
+            got = plan.run(prm, big[3 * k:3 * k + 3], want_nn=False)
+            assert np.array_equal(got["node_radius"], want_big[3 * k:3 * k + 3]), k
+        else:                                         # large tick: every node + the trajectory
+            got = plan.run(prm, big, coef, T, od, 0.0, 2.0, 0.02, want_nn=False)
+            assert np.array_equal(got["node_radius"], want_big), k
+            assert got["nsamples"] == 99 and got["nctrl"] == 21
+    plan.close()
+    c.close()

@@ -155,6 +155,18 @@ def test_pillar_map_known_answers():
     assert np.allclose(m.min(0), [-15.4, -15.8, 0.0], atol=1e-6) and np.allclose(m.max(0), [16.3, 15.5, 8.0], atol=1e-6)
 
 
+def test_scaled_pillar_map_reproduces_the_reference_sized_one():
+    """pillar_map_scaled (the clustered variant of the large configs) is the same generator on a wider square: at scale 1
+    it must give pillar_map()'s cloud point for point, in order; a wider world keeps the surface structure (points on the 0.1
+    lattice, heights up to 8 m) and grows with the area"""
+    m = synth.pillar_map()
+    assert np.array_equal(synth.pillar_map_scaled(1.0), m)
+    w = synth.pillar_map_scaled(2.0)
+    assert 3.0 < len(w) / len(m) < 5.0
+    assert np.array_equal(w, (np.round(w.astype(np.float64) / 0.1) * 0.1).astype(np.float32))
+    assert w[:, 2].min() == 0.0 and w[:, 2].max() <= 8.0 + 1e-6 and abs(w[:, :2]).max() < 33.0
+
+
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/Utils/kdtree/src/kdtree.c"),
                     reason="reference tree only exists in the build container")
 def test_port_vs_live_reference_random(oracle):
