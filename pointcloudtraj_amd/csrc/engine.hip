@@ -143,7 +143,8 @@ struct pct_cloud {
     bool has_pyr = false;
     PyrDesc P{};
     PyrNode *pyr_nodes = nullptr;
-    size_t pyr_cap = 0, pyr_total = 0;
+    unsigned char *pyr_hint = nullptr;          // start level of the walk per level-0 cell
+    size_t pyr_cap = 0, pyr_total = 0, pyr_hint_cap = 0;
     double empty_frac = 0.0;
     // grid
     bool has_grid = false;
@@ -174,6 +175,7 @@ struct pct_cloud {
     float *d_q = nullptr, *d_r = nullptr;
     double *d_q64 = nullptr, *d_r2 = nullptr, *d_d2 = nullptr, *d_radius = nullptr, *d_pts64 = nullptr;
     uint32_t *d_idx = nullptr, *d_count = nullptr, *d_bound = nullptr;
+    uint32_t *d_todo = nullptr;                                 // {count, ticket, slots...}: queries the fp32 pyramid walk leaves to the exact one
     unsigned char *d_skip = nullptr;
     double *d_part_d2 = nullptr;      // per-(query, block) partial minima of the streaming kernels: part_q x kMaxParts entries;
     uint32_t *d_part_idx = nullptr;   // larger batches go through them in slices of part_q queries
@@ -529,17 +531,18 @@ int build_pyramid(pct_cloud *c, const GridDesc &G)
     if (const char *e = std::getenv("PCT_PYRAMID_MIN_EMPTY")) min_empty = std::atof(e);
     if (mode == 0 || (mode < 0 && c->empty_frac < min_empty)) return PCT_OK;
     PyrDesc P{};
-    size_t total = 0;
-    int l = 0;
-    for (;; l++) {
-        if (l >= kPyrMaxLevels) return fail(PCT_ERR_INTERNAL, "pyramid deeper than %d levels", kPyrMaxLevels);
-        const int gx = pyr_dim(G.gx, l), gy = pyr_dim(G.gy, l), gz = pyr_dim(G.gz, l);
+    int nlev = 1;
+    while (pyr_dim(G.gx, nlev - 1) > 2 || pyr_dim(G.gy, nlev - 1) > 2 || pyr_dim(G.gz, nlev - 1) > 2) nlev++;
+    if (nlev > kPyrMaxLevels) return fail(PCT_ERR_INTERNAL, "pyramid deeper than %d levels", kPyrMaxLevels);
+    P.nlev = nlev;
+    // level l = blocks of 8 children per node of level l + 1 (pyramid.hpp): 8 * |grid of level l + 1| slots
+    size_t total = 0, nslots[kPyrMaxLevels] = {};
+    for (int l = 0; l < nlev; l++) {
+        nslots[l] = 8 * (size_t)pyr_dim(G.gx, l + 1) * pyr_dim(G.gy, l + 1) * pyr_dim(G.gz, l + 1);
         P.off[l] = (uint32_t)total;
-        total += (size_t)gx * gy * gz;
-        if (gx <= 2 && gy <= 2 && gz <= 2) break;
+        total += nslots[l];
     }
-    P.nlev = l + 1;
-    if (total > 0xFFFFFFF0ull) return PCT_OK;      // cannot be addressed with 32-bit node offsets: stay with the shell walk
+    if (total > 0xFFFFFFF0ull) return PCT_OK;      // cannot be addressed with 32-bit slot offsets: stay with the shell walk
     if (total > c->pyr_cap) {
         dev_free(c->pyr_nodes);
         c->pyr_cap = 0;
@@ -547,12 +550,16 @@ int build_pyramid(pct_cloud *c, const GridDesc &G)
         c->pyr_cap = total;
     }
     hipStream_t s = g_stream;
-    pyr_leaf_kernel<<<ceil_div((int64_t)G.ncells, 32), 256, 0, s>>>(G, c->sorted, c->cell_start, c->pyr_nodes, nullptr);
-    for (int k = 1; k < P.nlev; k++) {
-        const int gx = pyr_dim(G.gx, k), gy = pyr_dim(G.gy, k), gz = pyr_dim(G.gz, k);
-        pyr_up_kernel<<<ceil_div((int64_t)gx * gy * gz, 256), 256, 0, s>>>(gx, gy, gz, pyr_dim(G.gx, k - 1), pyr_dim(G.gy, k - 1), pyr_dim(G.gz, k - 1),
-                                                                            c->pyr_nodes + P.off[k - 1], c->pyr_nodes + P.off[k]);
+    pyr_leaf_kernel<<<ceil_div((int64_t)nslots[0], 32), 256, 0, s>>>(G, P, c->sorted, c->cell_start, c->pyr_nodes, (uint32_t)nslots[0]);
+    for (int l = 1; l < nlev; l++)
+        pyr_up_kernel<<<ceil_div((int64_t)nslots[l], 256), 256, 0, s>>>(G, P, l, c->pyr_nodes, (uint32_t)nslots[l]);
+    if ((size_t)G.ncells > c->pyr_hint_cap) {
+        dev_free(c->pyr_hint);
+        c->pyr_hint_cap = 0;
+        PCTCHK(dev_alloc(&c->pyr_hint, (size_t)G.ncells));
+        c->pyr_hint_cap = (size_t)G.ncells;
     }
+    pyr_hint_kernel<<<ceil_div((int64_t)G.ncells, 256), 256, 0, s>>>(G, P, c->pyr_nodes, c->pyr_hint);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
     c->P = P;
@@ -1032,14 +1039,30 @@ int nn_dev(pct_cloud *c, int algo, const float *d_q, int64_t Q, uint32_t *d_idx,
             static const bool wave_cube = [] { const char *e = std::getenv("PCT_COOP_WAVE_CUBE"); return e ? std::atoi(e) != 0 : true; }();
             const float4 *recs = perm ? c->d_qsorted : nullptr;
             if (c->has_pyr) {     // sparse occupancy: stage 0, then the bounding-box pyramid instead of cube + shells (pyramid.hpp)
-                if (c->count_work)
-                    nn_grid_pyr_kernel<true><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
-                else if (c->dom_valid && dom_ext_on()) {
-                    hipExtLaunchKernelGGL((nn_grid_pyr_kernel<false>), dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q,
-                                          (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
-                    dom_done(c);
-                } else
-                    nn_grid_pyr_kernel<false><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
+                // fp32 walk for everybody, then the exact walk for the (few) queries it lists as undecided; PCT_PYRAMID_EXACT=1:
+                // the exact walk for everybody (tests)
+                static const bool exact_only = [] { const char *e = std::getenv("PCT_PYRAMID_EXACT"); return e ? std::atoi(e) != 0 : false; }();
+                const int so_i = so ? 1 : 0;
+                if (exact_only) {
+                    if (c->count_work)
+                        nn_grid_pyr_kernel<true, false><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, nullptr);
+                    else
+                        nn_grid_pyr_kernel<false, false><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, nullptr);
+                } else {
+                    if (c->count_work)
+                        nn_grid_pyr_kernel<true, true><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, c->d_todo);
+                    else if (c->dom_valid && dom_ext_on()) {
+                        hipExtLaunchKernelGGL((nn_grid_pyr_kernel<false, true>), dim3(blocks), dim3(256), 0, s, c->ev2, c->ev3, 0, c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q,
+                                              (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, c->d_todo);
+                        dom_done(c);
+                    } else
+                        nn_grid_pyr_kernel<false, true><<<blocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, c->d_todo);
+                    const int tblocks = (int)std::min<int64_t>(256, blocks);
+                    if (c->count_work)
+                        nn_grid_pyr_todo_kernel<true><<<tblocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, c->d_todo);
+                    else
+                        nn_grid_pyr_todo_kernel<false><<<tblocks, 256, 0, s>>>(c->G, c->P, c->pyr_nodes, c->pyr_hint, c->sorted, c->cell_start, d_q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so_i, c->d_todo);
+                }
             } else if (c->count_work) {
                 if (wave_cube) nn_grid_coop_kernel<true, true><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
                 else nn_grid_coop_kernel<true, false><<<blocks, 256, 0, s>>>(c->G, c->sorted, c->cell_start, d_q, (uint32_t)Q, (uint32_t)c->index_base, recs, k_idx, k_d2, c->d_work, so ? 1 : 0);
@@ -1320,13 +1343,13 @@ int pct_cloud_destroy(pct_cloud *c)
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
-    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2);
+    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2); dev_free(c->d_todo);
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf);
     dev_free(c->d_coef); dev_free(c->d_segtime); dev_free(c->d_orders); dev_free(c->d_nsamples); dev_free(c->d_first_hit);
     dev_free(c->d_work);
-    dev_free(c->d_bbox); dev_free(c->d_gbcheck); dev_free(c->pyr_nodes);
+    dev_free(c->d_bbox); dev_free(c->d_gbcheck); dev_free(c->pyr_nodes); dev_free(c->pyr_hint);
     if (c->h_gbcheck) (void)hipHostFree(c->h_gbcheck);
     dev_free(c->ring_ht); dev_free(c->ring_slots); dev_free(c->ring_ovf); dev_free(c->ring_where); dev_free(c->ring_st);
     if (c->h_ring_status) (void)hipHostFree(c->h_ring_status);
@@ -1426,7 +1449,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     dev_free(c->d_q); dev_free(c->d_r); dev_free(c->d_q64); dev_free(c->d_r2); dev_free(c->d_d2); dev_free(c->d_radius);
     dev_free(c->d_pts64); dev_free(c->d_idx); dev_free(c->d_count); dev_free(c->d_skip); dev_free(c->d_bound);
     dev_free(c->d_part_d2); dev_free(c->d_part_idx); dev_free(c->d_cand_count); dev_free(c->d_cand_d2); dev_free(c->d_cand_idx); dev_free(c->d_ovf); dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey);
-    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2);
+    dev_free(c->d_inv); dev_free(c->d_sres_idx); dev_free(c->d_sres_d2); dev_free(c->d_todo);
     c->qcap = 0;
     c->generation++;                    // captured plans hold these pointers
     PCTCHK(dev_alloc(&c->d_q, 3 * q));
@@ -1448,6 +1471,8 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_inv, q));
     PCTCHK(dev_alloc(&c->d_sres_idx, q));
     PCTCHK(dev_alloc(&c->d_sres_d2, q));
+    PCTCHK(dev_alloc(&c->d_todo, q + 16));
+    HIPCHK(hipMemset(c->d_todo, 0, sizeof(uint32_t) * 16));            // count and ticket: the exact-walk kernel leaves them zero after every batch
     if (!c->d_sort1) {
         PCTCHK(dev_alloc(&c->d_sort1, 4 * kSortBuckets + 8));
         HIPCHK(hipMemset(c->d_sort1, 0, sizeof(uint32_t) * (4 * kSortBuckets + 8)));   // the sort keeps both sets of totals zero between batches

@@ -23,7 +23,7 @@ if stats:
         w.writerow(["kernel", "calls", "total_ns", "average_ns", "percent", "min_ns", "max_ns"])
         w.writerows(rows)
 pmc = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2"):
     fs = glob.glob(os.path.join(out, d, "*", "*_counter_collection.csv"))
     if not fs:
         continue
