@@ -4,8 +4,10 @@
  *
  * Replaces, call for call, the planner node's use of safeRegionRrtStar
  * (Planner/src/sim_planning_demo.cpp:143, 167, 346-347, 350, 354, 367, 399, 412-413, 416, 487, 761;
- * class surface Planner/include/pointcloudTraj/corridor_finder.h:81-149).  The wall-clock limits of
- * SafeRegionExpansion/Refine/Evaluate become iteration counts (deterministic runs).
+ * class surface Planner/include/pointcloudTraj/corridor_finder.h:81-149).  SafeRegionExpansion / Refine / Evaluate exist in both
+ * forms: `_timed` takes the reference's wall-clock limit in seconds (corridor_finder.h:97-99, read before every iteration as at
+ * corridor_finder.cpp:721-722, 774-775, 900-901, 950-951); the plain ones take iteration counts (deterministic runs).  A timed run
+ * reports the iterations it consumed; the plain run of that many iterations gives the identical tree.
  */
 #ifndef PCT_CORRIDOR_H
 #define PCT_CORRIDOR_H
@@ -33,6 +35,10 @@ int pct_corridor_reset_root(pct_corridor *c, const double target[3]);
 int pct_corridor_expansion(pct_corridor *c, int64_t iterations);
 int pct_corridor_refine(pct_corridor *c, int64_t iterations);
 int pct_corridor_evaluate(pct_corridor *c);
+/* SafeRegionExpansion / Refine / Evaluate (double time_limit), corridor_finder.h:97-99; iterations_done may be NULL */
+int pct_corridor_expansion_timed(pct_corridor *c, double time_limit, int64_t *iterations_done);
+int pct_corridor_refine_timed(pct_corridor *c, double time_limit, int64_t *iterations_done);
+int pct_corridor_evaluate_timed(pct_corridor *c, double time_limit);
 int pct_corridor_check_traj_pt_col(pct_corridor *c, const double p[3], int *collides);
 /* Path (k x 3, root first) and Radius (k); k through *n_out (may exceed cap; only cap rows written).
  * No path: the reference's placeholder, a 3x3 identity and three zero radii. */

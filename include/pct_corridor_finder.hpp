@@ -21,8 +21,10 @@
 // Numeric types follow data_type.h:12-51 (radius, g, f are float; coordinates double): that is part of the behaviour.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -263,8 +265,56 @@ public:
         sweep();
     }
 
-    // ---- :704-763 -- `iterations` replaces the wall-clock limit (capped by max_samples like the reference's loop) ----
-    void SafeRegionExpansion(int64_t iterations)
+    // ---- the reference's entry points, wall-clock boxed exactly as there (corridor_finder.h:97-99; the planner node calls them
+    // with seconds: sim_planning_demo.cpp:350, 412-413).  The clock is read before every iteration (corridor_finder.cpp:721-722,
+    // 774-775): inside a speculative batch that is before every REPLAYED sample, and a sample whose turn comes after the deadline
+    // is handed back to the generator, so a boxed run is, sample for sample, the iteration-count run of lastIterations(). ----
+    void SafeRegionExpansion(double time_limit)
+    {
+        start_clock(time_limit);
+        expand(max_samples_);
+        timed_ = false;
+    }
+    void SafeRegionRefine(double time_limit)
+    {
+        start_clock(time_limit);
+        last_iterations_ = grow(std::numeric_limits<int64_t>::max(), true);
+        timed_ = false;
+        sweep();
+        choose_route();
+    }
+    void SafeRegionEvaluate(double time_limit)
+    {
+        start_clock(time_limit);
+        evaluate();
+        timed_ = false;
+    }
+    // ---- the same three with iteration counts instead of the clock: deterministic runs (tests, benchmarks) ----
+    void ExpansionIterations(int64_t iterations) { timed_ = false; expand(std::min<int64_t>(iterations, max_samples_)); }   // capped by max_samples like :719
+    void RefineIterations(int64_t iterations)
+    {
+        timed_ = false;
+        last_iterations_ = grow(iterations, true);
+        sweep();
+        choose_route();
+    }
+    void EvaluateOnce() { timed_ = false; evaluate(); }
+    // samples consumed by the last Expansion / Refine call (the reference's iter_count)
+    int64_t lastIterations() const { return last_iterations_; }
+
+private:
+    using Clock = std::chrono::steady_clock;
+    void start_clock(double time_limit)
+    {
+        timed_ = true;
+        t_begin_ = Clock::now();
+        time_limit_ = time_limit;
+    }
+    double elapsed() const { return std::chrono::duration<double>(Clock::now() - t_begin_).count(); }
+    bool out_of_time() const { return timed_ && elapsed() > time_limit_; }                 // `(now - before).toSec() > time_limit`
+
+    // ---- :704-763 ----
+    void expand(int64_t iterations)
     {
         kd_ = kd_create(3);
         if (!kd_) throw std::runtime_error(std::string("kd_create: ") + pct_last_error());
@@ -272,21 +322,14 @@ public:
         root_ = T_.create(start_, (float)clearance(start_), 0.0f, (float)direct_);
         order_.push_back(root_);
         kd_add(root_);
-        grow(std::min<int64_t>(iterations, max_samples_), false);
-        sweep();
-        choose_route();
-    }
-    // ---- :765-815 ----
-    void SafeRegionRefine(int64_t iterations)
-    {
-        grow(iterations, true);
+        last_iterations_ = grow(iterations, false);
         sweep();
         choose_route();
     }
     // ---- :817-936: a new cloud has arrived; re-measure the route's spheres and cut what no longer holds.  The reference asks
     // checkRadius sphere by sphere (:835); the radii depend only on the centres and the cloud, so each pass is one batched
     // inflation whose answers the per-sphere logic then consumes in the reference's order. ----
-    void SafeRegionEvaluate()
+    void evaluate()
     {
         if (!path_exists_) return;
         std::vector<std::pair<Vec3, double>> broken;                  // (centre, radius before the update) of every sphere cut here
@@ -335,17 +378,18 @@ public:
             std::vector<int32_t> usable;
             for (int32_t e : goal_ids_) if (T_.alive[e] && touches_goal(e)) usable.push_back(e);
             goal_ids_ = usable;
-            if (usable.empty()) { path_exists_ = false; informed_ = false; best_cost_ = kInf; break; }
+            if (usable.empty() || out_of_time()) { path_exists_ = false; informed_ = false; best_cost_ = kInf; break; }      // :900-905
             pick_cheapest(usable);
             route_.clear();
             for (int32_t p = best_goal_; p != kNone; p = T_.parent[p]) route_.push_back(p);
         }
+        // what is left of the box goes to the repair pass (:931-935); it looks at the clock before every broken sphere (:950-951)
+        const double repair_limit = timed_ ? time_limit_ - elapsed() : 0.0;
         sweep();
-        repair_around(broken);
+        repair_around(broken, repair_limit);
         choose_route();
     }
 
-private:
     static constexpr int32_t kNone = detail::SphereArena::kNone;
     // how two spheres relate (corridor_finder.cpp:439-454): one inside the other / overlapping enough to fly through / neither
     static constexpr int kInside = 1, kLinked = -1, kApart = 0;
@@ -651,10 +695,11 @@ private:
     // that loop (spheres are only marked; the sweep runs after it) and a clearance is a pure function of the centre, so: ONE launch
     // finds the neighbourhood candidates of every broken sphere, ONE launch measures every sphere the loop could re-check, and the
     // per-sphere logic then runs on the host in the reference's order with those answers. ----
-    void repair_around(const std::vector<std::pair<Vec3, double>> &broken)
+    void repair_around(const std::vector<std::pair<Vec3, double>> &broken, double repair_limit)
     {
         const int K = (int)broken.size();
         if (K == 0) { sweep(); return; }
+        const Clock::time_point repair_begin = Clock::now();
         const int32_t n0 = kdx_size(kd_);
         const int cap = 256;
         std::vector<float> posf((size_t)3 * K), range((size_t)K);
@@ -699,6 +744,7 @@ private:
 
         std::vector<int32_t> kids;
         for (int i = 0; i < K; i++) {
+            if (timed_ && std::chrono::duration<double>(Clock::now() - repair_begin).count() > repair_limit) break;        // :950-951
             kdres *s = sets[(size_t)i];
             while (!kd_res_end(s)) {
                 const int32_t id = untag(kd_res_item_data(s));
@@ -736,15 +782,16 @@ private:
     }
 
     // ---- the sampling loops ----
-    void grow(int64_t iterations, bool refine)
+    int64_t grow(int64_t iterations, bool refine)
     {
         int64_t done = 0;
-        while (done < iterations) {
+        while (done < iterations && !out_of_time()) {
             if (ahead_ <= 1 && !fused_) { grow_one(draw(), refine); done++; continue; }      // three single queries per iteration
             // (with the fused kernel even K = 1 is one launch per iteration instead of three)
             const int K = (int)std::min<int64_t>(std::max(ahead_, 1), iterations - done);
             done += fused_ ? grow_fused(K, refine) : grow_staged(K, refine);
         }
+        return done;
     }
     void grow_one(const Vec3 &sample, bool refine)                     // one iteration of :719-756 / :772-808
     {
@@ -802,7 +849,7 @@ private:
             n_fused_launches_++;
             int i = pos;
             for (; i < K; i++) {
-                if (sampler_version_ != sampler0 || kd_version_ != kd0) { rng_.setState(la.rng_before[(size_t)i]); return i; }
+                if (sampler_version_ != sampler0 || kd_version_ != kd0 || out_of_time()) { rng_.setState(la.rng_before[(size_t)i]); return i; }
                 const pct_expand_result &e = res[(size_t)(i - pos)];
                 const int32_t n_now = kdx_size(kd_);
                 const int32_t slot = e.near_idx;
@@ -857,7 +904,7 @@ private:
         std::vector<int32_t> counts((size_t)K, -1);
         kdx_range_candidates_batch(kd_, cposf.data(), range.data(), K, ids.data(), cap, counts.data());
         for (int i = 0; i < K; i++) {
-            if (sampler_version_ != sampler0 || kd_version_ != kd0) { rng_.setState(la.rng_before[(size_t)i]); return i; }
+            if (sampler_version_ != sampler0 || kd_version_ != kd0 || out_of_time()) { rng_.setState(la.rng_before[(size_t)i]); return i; }
             if (slot[(size_t)i] < 0) { grow_one(la.sample[(size_t)i], refine); n_restarts_++; continue; }
             // the snapshot's winner stands unless a sphere added during this batch is strictly closer
             const float *qf = &posf[3 * (size_t)i];
@@ -902,6 +949,10 @@ private:
     std::vector<double> path_radii_;
     MinStdRand0 rng_;
     uint64_t n_clearance_ = 0, n_replayed_ = 0, n_restarts_ = 0, sampler_version_ = 0, kd_version_ = 0, n_fused_launches_ = 0, n_repair_trips_ = 0;
+    bool timed_ = false;            // the current call is wall-clock boxed
+    Clock::time_point t_begin_{};
+    double time_limit_ = 0.0;
+    int64_t last_iterations_ = 0;
     bool fused_ = true;             // one-launch expansion batches (kdx_expand_batch); false = the three-stage form
     int ahead_ = 256;               // results do not depend on it (tests/test_corridor.py); 1 = the reference's one-by-one loop.
                                     // Same box, C1 scenario: K = 16 / 64 / 256 -> 5.9 / 3.5 / 3.1 ms per replan (profiles/r02_corridor_probe.txt)

@@ -408,6 +408,7 @@ class PortCorridor:
         L.orrt_expansion.argtypes = [vp, C.c_int64]
         L.orrt_refine.argtypes = [vp, C.c_int64]
         L.orrt_evaluate.argtypes = [vp]
+        L.orrt_evaluate_exhausted.argtypes = [vp]
         L.orrt_reset_root.argtypes = [vp, d3]
         L.orrt_check_traj_pt_col.argtypes = [vp, d3]
         L.orrt_get_path.restype = C.c_int64
@@ -453,8 +454,14 @@ class PortCorridor:
     def SafeRegionRefine(self, iterations):
         self.L.orrt_refine(self.h, int(iterations))
 
-    def SafeRegionEvaluate(self):
-        self.L.orrt_evaluate(self.h)
+    def SafeRegionEvaluate(self, time_limit=None):
+        """time_limit None = no clock (iteration-count form); a negative limit = the clock has already run out at every check"""
+        if time_limit is None:
+            self.L.orrt_evaluate(self.h)
+        elif time_limit < 0:
+            self.L.orrt_evaluate_exhausted(self.h)
+        else:
+            raise ValueError("the CPU restatement states the time box only at its deterministic ends (None or < 0)")
 
     def checkTrajPtCol(self, p) -> bool:
         return bool(self.L.orrt_check_traj_pt_col(self.h, self._d3(p)))

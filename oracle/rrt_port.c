@@ -498,9 +498,15 @@ void orrt_refine(orrt *s, int64_t iterations)              /* :765-815 */
 
 typedef struct { double c[3]; double r; } failrec;
 
+/* The reference boxes Evaluate / treeRepair by wall clock (:900-901, :950-951).  A restatement cannot share a clock with the thing
+ * it checks, so it states the box at its two deterministic ends: 0 = the clock never runs out (iteration-count form), 1 = it has
+ * run out at every check -- the route is lost unless the first pass leaves it intact, and no broken sphere is repaired. */
+static int g_clock_exhausted = 0;
+
 static void tree_repair(orrt *s, failrec *fails, int nf)   /* :938-1021 */
 {
     for (int i = 0; i < nf; i++) {
+        if (g_clock_exhausted) break;                      /* :950-951 */
         float range = (float)fails[i].r * 2.0f;
         float pos[3] = { (float)fails[i].c[0], (float)fails[i].c[1], (float)fails[i].c[2] };
         okd_res *res = okd_nearest_rangef(s->tree, pos, range);
@@ -579,7 +585,7 @@ void orrt_evaluate(orrt *s)                                /* :817-936 */
         ivec feas = { 0, 0, 0 };
         for (int k = 0; k < s->EndList.n; k++) { int e = s->EndList.v[k]; if (s->nodes[e].valid && check_end(s, e)) iv_push(&feas, e); }
         iv_copy(&s->EndList, &feas);
-        if (feas.n == 0) {
+        if (feas.n == 0 || g_clock_exhausted) {            /* :900-905 */
             s->path_exist_status = 0; s->inform_status = 0; s->best_distance = RRT_INF;
             iv_free(&feas);
             break;
@@ -600,6 +606,13 @@ void orrt_evaluate(orrt *s)                                /* :817-936 */
     trace_path(s);
     free(fails);
 #undef PUSH_FAIL
+}
+
+void orrt_evaluate_exhausted(orrt *s)                      /* SafeRegionEvaluate(time_limit) with the limit already spent */
+{
+    g_clock_exhausted = 1;
+    orrt_evaluate(s);
+    g_clock_exhausted = 0;
 }
 
 static void solution_update(orrt *s, double cost_reduction, const double *target)     /* :272-296 */

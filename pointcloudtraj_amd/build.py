@@ -17,6 +17,7 @@ LIB = os.path.join(PKG, "lib")
 ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
 KDTREE_SO = os.path.join(LIB, "libkdtree.so")
 DEMO_BIN = os.path.join(LIB, "seam_demo")
+NODE_BIN = os.path.join(LIB, "node_call_sites")
 CORRIDOR_SO = os.path.join(LIB, "libpct_corridor.so")
 SHARD_SO = os.path.join(LIB, "libpct_shard.so")
 SHARD_CLIENT = os.path.join(LIB, "shard_client")
@@ -90,6 +91,15 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
         # the link line a planner node adds: -lpct_shard -lpct_engine (RCCL and the HIP runtime come in through libpct_shard.so)
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", SHARD_CLIENT, client_src,
                "-L" + LIB, "-lpct_shard", "-lpct_engine", "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
+               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    node_src = os.path.join(ROOT, "examples", "node_call_sites.cpp")
+    if os.path.exists(node_src) and os.path.exists(KDTREE_SO) and (force or _stale(NODE_BIN, [node_src, KDTREE_SO] + hdrs + cor_hdrs)):
+        # the planner node's own statements (sim_planning_demo.cpp:344-416) compiled against the replacement class
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", NODE_BIN, node_src,
+               "-L" + LIB, "-lkdtree", "-lpct_engine", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
                "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))

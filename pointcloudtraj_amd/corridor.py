@@ -40,6 +40,9 @@ def lib():
         L.pct_corridor_expansion.argtypes = [vp, C.c_int64]
         L.pct_corridor_refine.argtypes = [vp, C.c_int64]
         L.pct_corridor_evaluate.argtypes = [vp]
+        L.pct_corridor_expansion_timed.argtypes = [vp, C.c_double, C.POINTER(C.c_int64)]
+        L.pct_corridor_refine_timed.argtypes = [vp, C.c_double, C.POINTER(C.c_int64)]
+        L.pct_corridor_evaluate_timed.argtypes = [vp, C.c_double]
         L.pct_corridor_check_traj_pt_col.argtypes = [vp, d3, C.POINTER(C.c_int)]
         L.pct_corridor_get_path.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(C.c_int64)]
         L.pct_corridor_status.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]
@@ -109,14 +112,36 @@ class SafeRegionRrtStar:
     def resetRoot(self, target):
         self._chk(self.L.pct_corridor_reset_root(self.h, _d3(target)))
 
-    def SafeRegionExpansion(self, iterations):
+    # The reference's three entry points take seconds of wall clock (corridor_finder.h:97-99): pass a float.  An int is an
+    # iteration count (the deterministic form, C++: ExpansionIterations / RefineIterations / EvaluateOnce).  The timed forms return
+    # the number of samples they consumed.
+    def ExpansionIterations(self, iterations: int):
         self._chk(self.L.pct_corridor_expansion(self.h, int(iterations)))
 
-    def SafeRegionRefine(self, iterations):
+    def RefineIterations(self, iterations: int):
         self._chk(self.L.pct_corridor_refine(self.h, int(iterations)))
 
-    def SafeRegionEvaluate(self):
+    def EvaluateOnce(self):
         self._chk(self.L.pct_corridor_evaluate(self.h))
+
+    def SafeRegionExpansion(self, limit):
+        if isinstance(limit, (int, np.integer)):
+            return self.ExpansionIterations(limit)
+        n = C.c_int64()
+        self._chk(self.L.pct_corridor_expansion_timed(self.h, float(limit), C.byref(n)))
+        return n.value
+
+    def SafeRegionRefine(self, limit):
+        if isinstance(limit, (int, np.integer)):
+            return self.RefineIterations(limit)
+        n = C.c_int64()
+        self._chk(self.L.pct_corridor_refine_timed(self.h, float(limit), C.byref(n)))
+        return n.value
+
+    def SafeRegionEvaluate(self, time_limit=None):
+        if time_limit is None:
+            return self.EvaluateOnce()
+        self._chk(self.L.pct_corridor_evaluate_timed(self.h, float(time_limit)))
 
     def checkTrajPtCol(self, p) -> bool:
         c = C.c_int()

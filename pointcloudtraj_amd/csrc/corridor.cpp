@@ -76,9 +76,19 @@ int pct_corridor_set_start_pt(pct_corridor *c, const double start[3], const doub
     return guarded([&] { c->impl->setStartPt(v3(start), v3(end)); });
 }
 int pct_corridor_reset_root(pct_corridor *c, const double target[3]) { return guarded([&] { c->impl->resetRoot(v3(target)); }); }
-int pct_corridor_expansion(pct_corridor *c, int64_t iterations) { return guarded([&] { c->impl->SafeRegionExpansion(iterations); }); }
-int pct_corridor_refine(pct_corridor *c, int64_t iterations) { return guarded([&] { c->impl->SafeRegionRefine(iterations); }); }
-int pct_corridor_evaluate(pct_corridor *c) { return guarded([&] { c->impl->SafeRegionEvaluate(); }); }
+int pct_corridor_expansion(pct_corridor *c, int64_t iterations) { return guarded([&] { c->impl->ExpansionIterations(iterations); }); }
+int pct_corridor_refine(pct_corridor *c, int64_t iterations) { return guarded([&] { c->impl->RefineIterations(iterations); }); }
+int pct_corridor_evaluate(pct_corridor *c) { return guarded([&] { c->impl->EvaluateOnce(); }); }
+// the reference's own signatures: seconds of wall clock (corridor_finder.h:97-99)
+int pct_corridor_expansion_timed(pct_corridor *c, double time_limit, int64_t *iterations_done)
+{
+    return guarded([&] { c->impl->SafeRegionExpansion(time_limit); if (iterations_done) *iterations_done = c->impl->lastIterations(); });
+}
+int pct_corridor_refine_timed(pct_corridor *c, double time_limit, int64_t *iterations_done)
+{
+    return guarded([&] { c->impl->SafeRegionRefine(time_limit); if (iterations_done) *iterations_done = c->impl->lastIterations(); });
+}
+int pct_corridor_evaluate_timed(pct_corridor *c, double time_limit) { return guarded([&] { c->impl->SafeRegionEvaluate(time_limit); }); }
 int pct_corridor_check_traj_pt_col(pct_corridor *c, const double p[3], int *collides)
 {
     return guarded([&] { *collides = c->impl->checkTrajPtCol(v3(p)) ? 1 : 0; });

@@ -106,3 +106,67 @@ def test_gpu_commit_scenario_matches_oracle(oracle, speculation):
         assert np.array_equal(pw, pg), f"phase {k}: corridor centres differ"
         assert np.array_equal(rw, rg), f"phase {k}: corridor radii differ"
         assert sw["inflation_queries"] == sg["inflation_queries"], f"phase {k}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("speculation", [1, 256])
+def test_gpu_time_boxed_entry_points_equal_the_iteration_count_forms(oracle, speculation):
+    """SafeRegionExpansion / Refine / Evaluate(double time_limit) -- the reference's own signatures (corridor_finder.h:97-99, called
+    with seconds at sim_planning_demo.cpp:350, 412-413).  A boxed run reports the samples it consumed; a fresh finder given those
+    iteration counts must arrive at the identical tree and corridor (the clock is read before every replayed sample and an
+    unconsumed sample goes back to the generator), and so must the CPU restatement.  The Evaluate box is pinned at its deterministic
+    ends: ample time == EvaluateOnce, a spent box (negative limit) == the restatement's exhausted-clock form."""
+    from pointcloudtraj_amd import corridor, engine
+    from pointcloudtraj_amd.scenarios import BOUNDS, PARAMS as p, perturbed_cloud
+    engine.init(0)
+    cloud1 = sensed_cloud(12.0)
+
+    def prepare(f):
+        f.setParam(p["safety_margin"], p["search_margin"], p["max_radius"], p["sensing_range"])
+        f.setInput(cloud1)
+        f.reset()
+        f.setPt(START, GOAL, *BOUNDS, p["sensing_range"], p["max_samples"], p["sample_portion"], p["goal_portion"])
+
+    timed = corridor.SafeRegionRrtStar(80000)
+    timed.setSpeculation(speculation)
+    prepare(timed)
+    budget = 0.05 if speculation == 1 else 0.004        # seconds: a few hundred to a few thousand samples either way
+    n1 = timed.SafeRegionExpansion(float(budget))
+    snap = [(*timed.getPath(), timed.status())]
+    n2 = timed.SafeRegionRefine(float(budget) / 4)
+    snap.append((*timed.getPath(), timed.status()))
+    assert n1 > 50 and n2 > 10, (n1, n2)
+    assert snap[0][2]["path_exists"], "the budget must be large enough to find a corridor"
+    cloud2 = perturbed_cloud(cloud1, snap[-1][0])
+    timed.setInput(cloud2)
+    timed.SafeRegionEvaluate(60.0)                       # ample: the clock never interferes
+    snap.append((*timed.getPath(), timed.status()))
+    n3 = timed.SafeRegionRefine(float(budget) / 4)
+    snap.append((*timed.getPath(), timed.status()))
+
+    for make in (lambda: corridor.SafeRegionRrtStar(80000), lambda: oracle.PortCorridor()):
+        f = make()
+        if hasattr(f, "setSpeculation"):
+            f.setSpeculation(64)                         # a different batching on purpose
+        prepare(f)
+        f.SafeRegionExpansion(int(n1)); got = [(*f.getPath(), f.status())]
+        f.SafeRegionRefine(int(n2)); got.append((*f.getPath(), f.status()))
+        f.setInput(cloud2)
+        f.SafeRegionEvaluate(); got.append((*f.getPath(), f.status()))
+        f.SafeRegionRefine(int(n3)); got.append((*f.getPath(), f.status()))
+        for k, ((pa, ra, sa), (pb, rb, sb)) in enumerate(zip(snap, got)):
+            assert sa == sb, f"phase {k}: {sa} vs {sb}"
+            assert np.array_equal(pa, pb) and np.array_equal(ra, rb), f"phase {k}"
+
+    # a spent box: drastic second frame, the route breaks; with no time left the path is given up (:900-905) and nothing is repaired
+    cloud3 = sensed_cloud(16.0)
+    a, b = corridor.SafeRegionRrtStar(80000), oracle.PortCorridor()
+    for f in (a, b):
+        prepare(f)
+        f.SafeRegionExpansion(600); f.SafeRegionRefine(200)
+        f.setInput(cloud3)
+        f.SafeRegionEvaluate(-1.0)
+    assert a.status() == b.status()
+    pa, ra = a.getPath(); pb, rb = b.getPath()
+    assert np.array_equal(pa, pb) and np.array_equal(ra, rb)
+    assert a.repairBatches() == 0

@@ -135,6 +135,19 @@ def test_cpp_client_of_both_libraries():
     assert "all checks passed" in r.stdout
 
 
+def test_planner_node_call_sites_compile_and_run_against_the_replacement_class():
+    """examples/node_call_sites.cpp: sim_planning_demo.cpp:344-356, 381-416 with `_rrtPathPlaner` declared as
+    pct::SafeRegionRrtStar -- SafeRegionExpansion(_path_find_limit), SafeRegionRefine(_time_limit_1),
+    SafeRegionEvaluate(_time_limit_2) are the reference's own statements (wall-clock seconds, corridor_finder.h:97-99)"""
+    import os
+    import subprocess
+    from pointcloudtraj_amd import build
+    assert os.path.exists(build.NODE_BIN), "run __graft_entry__.build() first"
+    r = subprocess.run([build.NODE_BIN], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "initial corridor" in r.stdout and "all checks passed" in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("seed,n,lattice", [(1, 700, False), (2, 1500, True), (3, 70_000, False)])
 def test_differential_sequences_against_the_port(K, oracle, seed, n, lattice):
     """Random op sequences (insert bursts, kd_nearestf, kd_nearest_rangef with assorted radii, kd_clear + refill) on the
