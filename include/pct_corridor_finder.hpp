@@ -699,6 +699,7 @@ private:
     {
         const int K = (int)broken.size();
         if (K == 0) { sweep(); return; }
+        if (timed_ && repair_limit < 0.0) { sweep(); return; }       // the box was spent before the repair began (:950-951 at i = 0): no launch at all
         const Clock::time_point repair_begin = Clock::now();
         const int32_t n0 = kdx_size(kd_);
         const int cap = 256;
