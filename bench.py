@@ -4,8 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over one batch of synthetic queries: the batched 1-NN (pct_nn_batch_dev,
-include/pct_engine.h) of Q = 1,048,576 queries (seed 5) against the cloud resident in HBM, cell-pruned kernel
-(device-side query binning + nn_grid_coop_kernel).
+include/pct_engine.h) of Q = 1,048,576 queries against the cloud resident in HBM, cell-pruned kernel (device-side query
+binning + nn_grid_coop_kernel).  FOUR distinct query batches (seeds 5, 1005, 2005, 3005) are resident and step k answers
+batch k mod 4, so a step is never a replay of the previous one.  W warmup steps, then exactly K timed steps (barrier +
+synchronize on both sides); there is no other untimed repetition of the step -- the secondary probes of the line (streaming
+kernel, brute force, radius count, index build: GPU work the program does anyway) run BEFORE the warmup steps instead of after
+the timed region, so the card is not measured straight out of the idle state the host-side input generation leaves it in.
 
 N = 1 (config C3-throughput of SURVEY.md section 8(d), the configuration the metric is quoted on): 10,000,000 uniform points in
 [0,100)^3 (seed 3).
@@ -40,22 +44,131 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def measured_traffic(kernel: str):
-    """(HBM bytes per launch, file) of `kernel` from the newest committed PMC summary of this same command
-    (scripts/prof_r2.sh bench -> profiles/*_bench_pmc.json; 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate passes, the gfx950 correction of
-    MI355X_MICROARCH.md).  (None, None) when no summary is committed (PMC counters cannot be collected inside the timed run)."""
+def measured_counters(kernel: str, pattern: str = "*_bench_pmc.json", threads: int = 0):
+    """mean per-launch PMC counters of `kernel` from the newest committed summary matching `pattern` (rocprofv3 --pmc passes of this
+    same command, scripts/prof_bench.sh; one entry per kernel and grid size) -- ({counter: value}, file) or ({}, None).
+    threads: the launch's grid size in threads (8 x the batch for the cell-pruned kernels); 0 = the largest grid on file."""
     import glob
-    best, src = None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_pmc.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "*_final_pmc.json")))
-    for f in files:
+    import re
+    best, src, best_grid = {}, None, -1
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        found = None
         for k, v in d.items():
-            if kernel in k and "kernel<true" not in k and "derived_hbm_traffic_bytes_per_launch" in v:   # <true, ...> = instrumented twin
-                best, src = v["derived_hbm_traffic_bytes_per_launch"], "profiles/" + os.path.basename(f)
+            if kernel not in k or "kernel<true" in k:                # <true, ...> = the instrumented twin
+                continue
+            m = re.search(r"@grid=(\d+)", k)
+            g = int(m.group(1)) if m else 0
+            if (threads and g == threads) or (not threads and (found is None or g > found[0])) or (found is None and not m):
+                found = (g, v)
+        if found:
+            best = {c: (x["mean_per_launch"] if isinstance(x, dict) else x) for c, x in found[1].items()}
+            src, best_grid = "profiles/" + os.path.basename(f), found[0]
     return best, src
+
+
+def bound_from_counters(cnt):
+    """what limits the kernel by its SQ counters: 'latency' when the waves spend most of their cycles waiting (SQ_WAIT_ANY over
+    SQ_WAVE_CYCLES above one half), 'valu' when the vector ALU issues in most busy cycles, else 'hbm' (the roofline the fraction is
+    taken against).  None without counters."""
+    if not cnt or "SQ_WAVE_CYCLES" not in cnt:
+        return None, None
+    wait = cnt.get("SQ_WAIT_ANY", 0.0) / max(cnt["SQ_WAVE_CYCLES"], 1.0)
+    valu = cnt.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / max(cnt.get("SQ_BUSY_CYCLES", 0.0) * 4.0, 1.0)      # issue slots of 4 SIMDs per CU-cycle
+    detail = {"wait_fraction_of_wave_cycles": wait, "valu_issue_per_busy_cycle": valu, "l2_hit_rate": cnt.get("derived_l2_hit_rate")}
+    return ("latency" if wait > 0.5 else "hbm"), detail
+
+
+def clustered_probe(E, synth, torch, device, Q, steps=10):
+    """"all clouds are also run in a clustered variant (points on 0.1-grid pillar surfaces a la map_generator)".
+    The reference's own world (seed 6, 182,332 points) and the same generator on a 7.4 times wider square (10.2 M points), uniform
+    queries over the bounding box, two distinct batches alternating.  Such clouds carry the bounding-box pyramid (pyramid.hpp); the
+    small one is also run with the plain shell walk for comparison."""
+    out = {}
+    for name, make in (("pillar_map_seed6", synth.pillar_map), ("pillar_map_x7.4_10M", lambda: synth.pillar_map_scaled(7.4))):
+        pts = make()
+        lo, hi = pts.min(0), pts.max(0)
+        qs = [torch.from_numpy((lo + synth.uniform01_f32(77 + 1000 * b, 3 * Q).reshape(Q, 3) * (hi - lo)).astype(np.float32)).to(device) for b in range(2)]
+        oi = torch.empty(Q, dtype=torch.int32, device=device)
+        od = torch.empty(Q, dtype=torch.float64, device=device)
+        cs = torch.cuda.current_stream().cuda_stream
+        legs = {}
+        with E.Cloud(len(pts)) as c:
+            c.set_input(pts)
+            c.reserve_queries(Q)
+            for mode in (("pyramid", None),) + ((("shell_walk", "0"),) if len(pts) < 1_000_000 else ()):
+                if mode[1] is not None:
+                    os.environ["PCT_PYRAMID"] = mode[1]
+                t0 = time.perf_counter()
+                c.build_grid()
+                E.sync()
+                t_build = 1e3 * (time.perf_counter() - t0)
+                os.environ.pop("PCT_PYRAMID", None)
+                for k in range(3):
+                    c.nn_device(qs[k % 2].data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs, E.ALGO_GRID)
+                torch.cuda.synchronize()
+                c.set_timing_stride(1)
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    c.nn_device(qs[k % 2].data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs, E.ALGO_GRID)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t0) / steps
+                km = float(np.mean(c.kernel_ms_history(steps)))
+                c.set_work_counters(True)
+                w = np.zeros(3)
+                for b in range(2):
+                    c.nn_device(qs[b].data_ptr(), Q, oi.data_ptr(), od.data_ptr(), cs, E.ALGO_GRID)
+                    torch.cuda.synchronize()
+                    w += np.asarray(c.last_work_ex(), np.float64) / 2
+                c.set_work_counters(False)
+                # parity inside the run: a slice of the batch against the all-fp64 streaming kernel
+                bi, bd = c.nn(qs[1][:2048].cpu().numpy(), E.ALGO_STREAM)
+                same = bool(np.array_equal(bi, oi[:2048].cpu().numpy().view(np.uint32)) and np.array_equal(bd, od[:2048].cpu().numpy()))
+                alg = 12 * w[0] + 8 * w[1] + 192 * w[2] + 24 * Q
+                pi = c.pyramid_info()
+                legs[mode[0]] = {"index_build_ms": t_build, "ms_per_step": ms, "queries_per_s": Q / (ms * 1e-3), "kernel_ms": km,
+                                 "kernel": "nn_grid_pyr_kernel (+ nn_grid_pyr_todo_kernel)" if pi["levels"] else "nn_grid_coop_kernel",
+                                 "points_per_query": w[0] / Q, "cell_runs_per_query": w[1] / Q, "pyramid_node_visits_per_query": w[2] / Q,
+                                 "algorithmic_bytes": int(alg), "algorithmic_bytes_rule": "12 B x points scanned + 8 B x cell runs + 192 B x node visits (8 boxes of 6 floats) + 24 B x Q",
+                                 "achieved_GBs": alg / (km * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (km * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "pyramid_levels": pi["levels"], "empty_cell_fraction": pi["empty_fraction"], "grid": c.grid_info(),
+                                 "equals_streaming_kernel_on_2048_queries": same}
+        out[name] = {"points": int(len(pts)), "queries_per_step": Q, **legs}
+        del qs, oi, od
+    return out
+
+
+def c1_stated_probe(E, oracle_mod):
+    """Config C1 exactly as SURVEY 8(d) states it: the seed-6 map cropped to the 9,383 points within 5 m of the start pose,
+    clean_demo.launch constants, corridor RNG seed 0, 2,000 SafeRegionExpansion iterations -- corridor-generation ms on the engine
+    (speculative batches, fused launches) and on the CPU restatement over the kd-tree port, same corridor required."""
+    from pointcloudtraj_amd import corridor, scenarios, synth
+    p = scenarios.PARAMS
+    cloud = synth.crop_ball(synth.pillar_map(), scenarios.START, 5.0)
+
+    def run(f):
+        f.setParam(p["safety_margin"], p["search_margin"], p["max_radius"], p["sensing_range"])
+        t0 = time.perf_counter()
+        f.setInput(cloud)
+        t1 = time.perf_counter()
+        f.reset()
+        f.setPt(scenarios.START, scenarios.GOAL, *scenarios.BOUNDS, p["sensing_range"], p["max_samples"], p["sample_portion"], p["goal_portion"])
+        f.SafeRegionExpansion(2000)
+        t2 = time.perf_counter()
+        return 1e3 * (t1 - t0), 1e3 * (t2 - t1), f.getPath(), f.status()
+
+    if oracle_mod is None:                                          # the engine's side (run while the card is busy with the other probes)
+        run(corridor.SafeRegionRrtStar(20000))                      # warm-up: first launches, allocations
+        gs = [run(corridor.SafeRegionRrtStar(20000)) for _ in range(5)]
+        g = sorted(gs, key=lambda r: r[1])[len(gs) // 2]
+        return {"what": "C1 as stated: 9,383-point crop (5 m around the start) of the seed-6 map, clean_demo.launch constants, RNG seed 0, SafeRegionExpansion(2000 iterations); median of 5 runs",
+                "cloud_points": int(len(cloud)), "set_input_ms": g[0], "expansion_2000_ms": g[1], "status": g[3], "path_len": int(len(g[2][0])),
+                "_path": g[2]}
+    c = run(oracle_mod.PortCorridor())                              # the CPU restatement's side
+    return {"set_input_ms": c[0], "expansion_2000_ms": c[1], "cores": 1, "_path": c[2], "status": c[3]}
 
 
 def replan_probe(E, synth, ticks=200):
@@ -203,6 +316,9 @@ def c4_probe(E, synth, torch, device, Q):
         ps4, runs4 = c4.last_work()
         c4.set_work_counters(False)
         alg4 = 12 * ps4 + 8 * runs4 + 24 * Q
+        cnt4, src4 = measured_counters("nn_grid_coop_kernel", "*_c4_pmc.json", threads=8 * Q)       # scripts/probe_c4.py under rocprofv3
+        tr4 = cnt4.get("derived_hbm_traffic_bytes_per_launch")
+        bound4, detail4 = bound_from_counters(cnt4)
         del qd, oi, od
     out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted, beyond the 256 MiB Infinity Cache)",
                        "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_4096_queries_ms_host_buffers": float(np.median(ts)),
@@ -211,7 +327,13 @@ def c4_probe(E, synth, torch, device, Q):
                        "stream_kernel": {"kernel": "nn_stream_kernel<QT> (all-fp64, one pass over the SoA cloud)", "points": sp},
                        "grid_throughput": {"queries": Q, "ms_per_step": step4, "queries_per_s": Q / (step4 * 1e-3), "kernel": "nn_grid_coop_kernel",
                                            "kernel_ms": k4, "algorithmic_bytes": int(alg4), "achieved_GBs": alg4 / (k4 * 1e-3) / 1e9,
-                                           "frac_of_hbm_peak": alg4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "points_scanned": int(ps4), "cell_runs": int(runs4)}}
+                                           "frac_of_hbm_peak": alg4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS, "points_scanned": int(ps4), "cell_runs": int(runs4),
+                                           "bound": bound4 or "hbm", "bound_evidence": detail4, "traffic": tr4, "traffic_source": src4,
+                                           "frac_of_measured_traffic": (tr4 / (k4 * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr4 else None,
+                                           "note": "DRAM-resident: one query touches ~10 cache lines of 16-byte records (4 x-runs of ~12 records, each "
+                                                   "starting anywhere in a line: 1 + 192/128 lines per run) that no other query of the batch shares "
+                                                   "(1 M queries over 16.7 M cells), so the fabric traffic is ~1.7x the 12-byte-rule bytes by line "
+                                                   "granularity alone; DESIGN.md section 4"}}
     del p4
     return out["c4_probe"]
 
@@ -222,9 +344,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--preheat-steps", type=int, default=-1,
-                    help="untimed passes of the same step BEFORE the warmup steps, to bring the card out of its idle power state (-1: 1500 "
-                         "at N = 1, 300 at N > 1; 0 = none).  The same count on every rank (each pass holds a collective at N > 1)")
+    ap.add_argument("--preheat-steps", type=int, default=0,
+                    help="extra untimed passes of the step before the W warmup steps (default none; reported in the line).  The same count on "
+                         "every rank (each pass holds a collective at N > 1)")
     ap.add_argument("--points", type=int, default=10_000_000, help="points of the N = 1 cloud (config C3)")
     ap.add_argument("--points-total", type=int, default=100_000_000, help="points of the N > 1 cloud (config C4), split over the ranks")
     ap.add_argument("--queries", type=int, default=1 << 20)
@@ -234,6 +356,7 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=0, help="points in the host kd-tree (0 = same as --points)")
     ap.add_argument("--stream-probe", type=int, default=1, help="also time the streaming / brute-force / corridor probes (0 = skip)")
     ap.add_argument("--replan-probe", type=int, default=1, help="config C5: rolling 5M-point cloud, 20 Hz replan ticks (0 = skip)")
+    ap.add_argument("--clustered-probe", type=int, default=1, help="N = 1: the clustered (pillar-surface) variants of the clouds, SURVEY 8(d) (0 = skip)")
     ap.add_argument("--c4-probe", type=int, default=1, help="N = 1: also run the 100 M-point cloud (config C4) on this one card (0 = skip)")
     ap.add_argument("--spatial-leg", type=int, default=1, help="N > 1: also time the batch with spatially routed queries (0 = skip)")
     ap.add_argument("--one-gpu-ref", type=int, default=1, help="N > 1: rank 0 also times the batch against the whole cloud on its one card (0 = skip)")
@@ -336,6 +459,110 @@ def timed_batches(sc, q, algo, reps, barrier):
     return 1e3 * (time.perf_counter() - t0) / reps
 
 
+def gpu_probes(a, E, synth, torch, sc, q, local_pts, Q):
+    """N = 1 secondary figures on the headline cloud (they run BEFORE the warmup steps: see the module docstring)"""
+    out = {}
+    cs = torch.cuda.current_stream().cuda_stream
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        ms = []
+        for _ in range(reps):
+            fn()
+            ms.append(sc.cloud.last_kernel_ms())
+        return float(np.median(ms))
+
+    # (a) streaming kernel at its HBM-bound operating points: the SoA cloud is read once per pass
+    probes = []
+    for qn in (1, 2, 4):
+        ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 20)
+        sb = 12 * len(local_pts) + 24 * qn
+        probes.append({"queries": qn, "kernel_ms": ms, "algorithmic_bytes": sb, "achieved_GBs": sb / (ms * 1e-3) / 1e9,
+                       "frac_of_hbm_peak": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    out["stream_probe"] = {"kernel": "nn_stream_kernel<QT> + nn_reduce_partials_kernel (all-fp64, one pass over the SoA cloud)",
+                           "points": probes}
+    # (b) brute force at config C2's batch size: packed-fp32 filter with the points in registers + exact fp64 recheck
+    qn = 4096
+    ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 5)
+    out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + brute2_prep_kernel + tile_reg_kernel<false> (expanded-form packed-fp32 filter, points in registers, exact fp64 recheck) + nn_reduce_candidates_kernel",
+                                "queries": qn, "kernel_ms": ms, "queries_per_s": qn / (ms * 1e-3),
+                                "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
+                                "algorithmic_flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}
+    # the same batch as a radius count (kd_nearest_range + kd_res_size semantics) through the brute-force family
+    r4 = torch.full((qn,), 1.0, dtype=torch.float32, device=sc.device)
+    cnt4 = torch.empty(qn, dtype=torch.int32, device=sc.device)
+    ms = timed(lambda: sc.cloud.radius_count_device(q.data_ptr(), r4.data_ptr(), qn, cnt4.data_ptr(), cs, E.ALGO_STREAM), 5)
+    out["brute_force_count_probe"] = {"kernel": "brute2_prep_count_kernel + tile_reg_kernel<true> (same filter, exact fp64 test of what may lie inside the ball)",
+                                      "queries": qn, "radius": 1.0, "kernel_ms": ms, "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
+                                      "mean_count": float(cnt4.double().mean().item())}
+    del r4, cnt4
+    # (c) corridor side (config C3): sphere inflation of 200 seeds against the 10M-point cloud through the
+    # host-buffer entry point (PCIe and launch latency included) -- ms per pass
+    seeds = synth.uniform_points(4, 200, 10.0, 90.0).astype(np.float64)
+    prm = E.inflate_params((50.0, 50.0, 50.0), 1.0e9, 0.25, 1.5)
+    for _ in range(3):
+        sc.cloud.inflate(prm, seeds)
+    ts = []
+    for _ in range(20):
+        t1 = time.perf_counter()
+        sc.cloud.inflate(prm, seeds)
+        ts.append(1e3 * (time.perf_counter() - t1))
+    out["corridor_probe"] = {"what": "pct_inflate_batch, 200 seeds (seed 4), search_margin 0.25, max_radius 1.5, host buffers",
+                             "ms_per_pass_median": float(np.median(ts)), "ms_per_pass_p99": float(np.percentile(ts, 99))}
+    if sc.cloud.has_grid:
+        # radius count through the index (kd_nearest_range + kd_res_size semantics, d2 <= r*r), same cloud and query batch
+        r1 = torch.full((Q,), 1.0, dtype=torch.float32, device=sc.device)
+        ts = []
+        for k in range(6):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            cnt = sc.radius_count(q, r1)
+            torch.cuda.synchronize()
+            if k:
+                ts.append(time.perf_counter() - t1)
+        out["radius_count_probe"] = {"what": f"pct_radius_count_batch_dev, {Q} queries, r = 1.0, cell-pruned cooperative kernel",
+                                     "ms_per_batch": 1e3 * float(np.median(ts)), "queries_per_s": Q / float(np.median(ts)),
+                                     "mean_count": float(cnt.double().mean().item())}
+        del r1, cnt
+    # config C2: 1 M uniform points (seed 1), 4096 queries (seed 2), host buffers in and out (PCIe + launch latency included)
+    p2 = synth.uniform_points(1, 1_000_000, 0.0, 100.0)
+    q2 = synth.uniform_points(2, 4096, 0.0, 100.0)
+    with E.Cloud(len(p2)) as c2:
+        c2.set_input(p2)
+
+        def med(fn, n=7):
+            ts = []
+            for k in range(n):
+                t1 = time.perf_counter()
+                fn()
+                if k:
+                    ts.append(1e3 * (time.perf_counter() - t1))
+            return float(np.median(ts))
+        brute_ms = med(lambda: c2.nn(q2, E.ALGO_STREAM))
+        build_ms = med(lambda: c2.build_grid(), 4)
+        grid_ms = med(lambda: c2.nn(q2, E.ALGO_GRID))
+    out["c2_probe"] = {"what": "C2: 1,000,000 uniform points, 4096 NN queries, host buffers (pct_nn_batch_algo)",
+                       "brute_force_ms": brute_ms, "pair_evals_per_s": 4096 * 1e6 / (brute_ms * 1e-3),
+                       "index_build_ms": build_ms, "indexed_ms": grid_ms, "indexed_queries_per_s": 4096 / (grid_ms * 1e-3)}
+    if a.algo == "grid":
+        # the per-frame index build on the headline cloud (setInput's rebuild, corridor_finder.cpp:93-99): bounding box + two-level LDS
+        # counting sort into cells, points already resident in HBM; wall clock around pct_cloud_build_grid (it ends synchronised)
+        tb = []
+        for _ in range(6):
+            E.sync()
+            t1 = time.perf_counter()
+            sc.cloud.build_grid(a.cell)
+            tb.append(1e3 * (time.perf_counter() - t1))
+        bm = float(np.median(tb[1:]))
+        out["index_build_probe"] = {"what": f"pct_cloud_build_grid on the {len(local_pts)}-point cloud resident in HBM (bbox + gb_hist + gb_scatter + gb_cells, self-check read back)",
+                                    "ms_median": bm, "points_per_s": len(local_pts) / (bm * 1e-3)}
+    return out
+
+
+QUERY_SEEDS = (5, 1005, 2005, 3005)        # the step's batches: step k answers batch k mod 4
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -365,35 +592,43 @@ def main():
         sc.build_grid(a.cell)
     E.sync()
     t_grid = time.perf_counter() - t0
-    q_host = synth.uniform_points(5, Q, 0.0, side)
+    q_hosts = [synth.uniform_points(sd, Q, 0.0, side) for sd in QUERY_SEEDS]
     sc.reserve(Q)
-    q = torch.from_numpy(q_host).to(sc.device)
+    qs = [torch.from_numpy(h).to(sc.device) for h in q_hosts]
+    q = qs[0]
 
     def barrier():
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
 
-    kern_ms = []
-    # the dominant kernel's duration is sampled on every 4th launch of the timed region (the kernel's own begin / end timestamps,
-    # read after the closing barrier); timing every launch costs ~4 us of each 160 us step
-    sc.cloud.set_timing_stride(4)
-    # The card idles (low clocks) while the host generates the inputs above; a handful of 0.16 ms warmup steps does not bring it back:
-    # same box, --steps 20: --warmup 5 / 50 / 500 -> 0.167 / 0.158 / 0.151 ms per step (kernel 0.138 / 0.131 / 0.123).  So the same
-    # step is run untimed for ~0.25 s first; the W warmup steps and the K timed steps follow as the contract says.
-    preheat = a.preheat_steps if a.preheat_steps >= 0 else (300 if c4 else 1500)
-    for _ in range(preheat):
-        sc.nn_submit(q, algo)
-    for _ in range(a.warmup):
-        sc.nn_submit(q, algo)
+    # ---- N = 1: the secondary probes on the same cloud, and the instrumented (work-counting) pass of every batch ----
+    pre = {}
+    if a.stream_probe and world == 1:
+        pre = gpu_probes(a, E, synth, torch, sc, q, local_pts, Q)
+    sc.cloud.set_work_counters(True)
+    pts_scanned = runs = 0.0
+    for b in range(len(qs)):
+        sc.nn_local(qs[b], algo)
+        torch.cuda.synchronize()
+        w = sc.cloud.last_work()
+        pts_scanned += w[0] / len(qs)
+        runs += w[1] / len(qs)
+    sc.cloud.set_work_counters(False)
+
+    # ---- the measured region: W warmup steps, then exactly K timed steps; the dominant kernel's duration is sampled on every 4th
+    # timed launch (the kernel's own begin / end timestamps, read after the closing barrier) ----
+    preheat = max(a.preheat_steps, 0)                 # opt-in extra untimed steps (default none); reported in the line
+    for k in range(preheat + a.warmup):
+        sc.nn_submit(qs[k % len(qs)], algo)
     barrier()
-    sc.cloud.set_timing_stride(4)                     # restart the stride: the first timed step is a sampled one
+    sc.cloud.set_timing_stride(4)                     # the first timed step is a sampled one
     samples0 = sc.cloud.kernel_ms_samples()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
         # at N > 1 the exchange step of batch k runs on a side stream under the kernels of batch k+1 (dist.nn_submit);
         # the closing barrier + synchronize waits for every batch's merged answer
-        d2, idx, done = sc.nn_submit(q, algo)
+        sc.nn_submit(qs[k % len(qs)], algo)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -401,28 +636,14 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / a.steps
-    d2_keep, idx_keep = d2.clone(), idx.clone()       # the result slots are reused by the probes below
-
-    # dominant-kernel time: HIP events the engine recorded on the launch stream around every launch of the TIMED region
-    # (the engine keeps the last 64 pairs; with more steps than that, the most recent 64 of them)
     n_samples = sc.cloud.kernel_ms_samples() - samples0
     kern_ms = sc.cloud.kernel_ms_history(max(1, min(n_samples, 64)))
     sc.cloud.set_timing_stride(1)
     k_ms = float(np.mean(kern_ms))
-    # all kernels of one batch (sort + search), from a few extra untimed passes
-    batch_ms = []
-    sc.cloud.set_timing(2)                      # whole-batch events are opt-in (they cost ~9 us per batch)
-    for _ in range(3):
-        sc.nn_local(q, algo)
-        batch_ms.append(sc.cloud.last_batch_ms())
-    sc.cloud.set_timing(1)
-    b_ms = float(np.mean(batch_ms))
-    # algorithmic work of one launch (separate instrumented pass)
-    sc.cloud.set_work_counters(True)
-    sc.nn_local(q, algo)
-    torch.cuda.synchronize()
-    pts_scanned, runs = sc.cloud.last_work()
-    sc.cloud.set_work_counters(False)
+    # answers of batch 0 for the parity checks below (untimed)
+    d2, idx, done = sc.nn_submit(q, algo)
+    barrier()
+    d2_keep, idx_keep = d2.clone(), idx.clone()       # the result slots are reused by the probes below
     # 12 B per point scanned (3 x fp32) + 8 B per examined cell run + 12 B per query in + 12 B out
     bytes_alg = 12 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else 12 * len(local_pts) * ((Q + 7) // 8) + 24 * Q
     bytes_rec = 16 * pts_scanned + 8 * runs + 24 * Q if algo == E.ALGO_GRID else bytes_alg   # what the 16-byte {x,y,z,index} records move
@@ -470,7 +691,6 @@ def main():
         # strong-scaling base in the same run: rank 0's card alone holds the WHOLE cloud and answers the same batch
         if rank == 0:
             with E.Cloud(n_total) as whole:
-                off = 0
                 first = True
                 for o, blk in synth.uniform_points_chunked(cloud_seed, n_total, 0.0, side):
                     (whole.set_input if first else whole.append)(blk)
@@ -498,9 +718,12 @@ def main():
             tdist.destroy_process_group()
         return
 
-    traffic, traffic_src = measured_traffic("nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel")
+    kname = "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel"
+    cnt, cnt_src = measured_counters(kname, threads=8 * Q)
+    traffic = cnt.get("derived_hbm_traffic_bytes_per_launch")
     if c4:
-        traffic, traffic_src = None, None            # the committed PMC passes are of the N = 1 command
+        cnt, cnt_src, traffic = {}, None, None       # the committed PMC passes are of the N = 1 command
+    bound, bound_detail = bound_from_counters(cnt)
     value = Q / elapsed * a.steps                    # merged answers per second (never multiplied by the rank count)
     out = {
         "metric": "nn_queries_per_sec_10M_point_cloud",
@@ -509,7 +732,6 @@ def main():
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
-        "preheat_steps": preheat,           # untimed passes of the same step before the warmup steps (power state; see main())
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "strong" if c4 else "weak",
@@ -518,12 +740,15 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"C4: ONE cloud of {n_total} uniform fp32 points in [0,{side:.0f})^3 (seed 6) sharded by contiguous index range over {world} "
-                         f"GPU(s) ({sc.end - sc.begin} points on rank 0), {Q} uniform NN queries per step (seed 5) replicated, {a.algo} kernel per shard, "
-                         "all_reduce(min) merge; value = merged answers/s"
+                         f"GPU(s) ({sc.end - sc.begin} points on rank 0), {Q} uniform NN queries per step ({len(qs)} distinct batches in rotation, seeds "
+                         f"{list(QUERY_SEEDS)}) replicated, {a.algo} kernel per shard, all_reduce(min) merge; value = merged answers/s"
                          if c4 else
-                         f"C3-throughput: {a.points} uniform fp32 points in [0,{side:.1f})^3 (seed 3), "
-                         f"{Q} uniform NN queries per step (seed 5), {a.algo} kernel, inputs resident in HBM"),
+                         f"C3-throughput: {a.points} uniform fp32 points in [0,{side:.1f})^3 (seed 3), {Q} uniform NN queries per step "
+                         f"({len(qs)} distinct batches in rotation, seeds {list(QUERY_SEEDS)}), {a.algo} kernel, inputs resident in HBM"),
             "points_per_gpu": sc.end - sc.begin, "total_points": n_total, "queries_per_step": Q, "algo": a.algo,
+            "query_batches_in_rotation": len(qs), "extra_untimed_steps_before_warmup": preheat,
+            "gpu_work_before_the_warmup_steps": ("the line's secondary probes on the same cloud (streaming kernel, brute force, radius count, C2, index "
+                                                 "rebuild) and one instrumented pass per query batch" if pre else "one instrumented pass per query batch"),
             "query_shard_evaluations_per_s": world * value,
             "parallelism": (f"cloud sharded by contiguous index range over {world} GPU(s), queries replicated, all_reduce(min) merge"
                             if world > 1 else "single GPU"),
@@ -533,19 +758,21 @@ def main():
             "grid_build_s": round(t_grid, 4),
         },
         "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src,
+            "bound": bound or "hbm", "roofline": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": cnt_src,
             "frac_of_measured_traffic": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "kernel": "nn_grid_coop_kernel" if algo == E.ALGO_GRID else "nn_tile_candidates_kernel",
-            "kernel_ms": k_ms, "kernel_launches_timed": len(kern_ms), "batch_kernels_ms": b_ms,
-            "algorithmic_bytes": int(bytes_alg), "algorithmic_bytes_rule": "SURVEY 8(d): 12 B x points scanned + 8 B x cell runs + 24 B x Q",
+            "bound_evidence": bound_detail,
+            "kernel": kname,
+            "kernel_ms": k_ms, "kernel_launches_timed": len(kern_ms), "other_kernels_and_launch_gaps_ms": max(ms_per_step - k_ms, 0.0),
+            "algorithmic_bytes": int(bytes_alg), "algorithmic_bytes_rule": "SURVEY 8(d): 12 B x points scanned + 8 B x cell runs + 24 B x Q (mean over the batches in rotation)",
             "record_bytes": int(bytes_rec), "achieved_with_16B_records": bytes_rec / (k_ms * 1e-3) / 1e9,
             "points_scanned": int(pts_scanned), "cell_runs": int(runs), "pair_evals_per_s": pts_scanned / (k_ms * 1e-3),
             "note": ("gather kernel: `frac` = algorithmic bytes / kernel time / 8 TB/s; the 10 M-point cloud (160 MB cell-sorted) stays in the 256 MiB "
-                     "Infinity Cache, so the bytes that reach the fabric are `traffic` (frac_of_measured_traffic); the DRAM-resident figures are in "
-                     "c4_probe (100 M-point cloud) and stream_probe"),
+                     "Infinity Cache, so the bytes that reach the fabric are `traffic` (frac_of_measured_traffic) and `bound` says what the SQ counters "
+                     "of the committed profile say; the DRAM-resident figures are in c4_probe (100 M-point cloud) and stream_probe"),
         },
     }
+    out.update(pre)
     if c4_legs:
         out["c4_q4096"] = c4_legs
     if spatial:
@@ -553,116 +780,17 @@ def main():
     if one_gpu:
         out["one_gpu_whole_cloud"] = dict(one_gpu, speedup_of_this_run=value / one_gpu["answers_per_s"])
 
-    if a.stream_probe and world == 1:
-        cs = torch.cuda.current_stream().cuda_stream
-
-        def timed(fn, reps):
-            for _ in range(2):
-                fn()
-            ms = []
-            for _ in range(reps):
-                fn()
-                ms.append(sc.cloud.last_kernel_ms())
-            return float(np.median(ms))
-
-        # (a) streaming kernel at its HBM-bound operating points: the SoA cloud is read once per pass
-        probes = []
-        for qn in (1, 2, 4):
-            ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 20)
-            sb = 12 * len(local_pts) + 24 * qn
-            probes.append({"queries": qn, "kernel_ms": ms, "algorithmic_bytes": sb, "achieved_GBs": sb / (ms * 1e-3) / 1e9,
-                           "frac_of_hbm_peak": sb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
-        out["stream_probe"] = {"kernel": "nn_stream_kernel<QT> + nn_reduce_partials_kernel (all-fp64, one pass over the SoA cloud)",
-                               "points": probes}
-        # (b) brute force at config C2's batch size: LDS-tiled packed-fp32 filter + exact fp64 recheck
-        qn = 4096
-        ms = timed(lambda: sc.cloud.nn_device(q.data_ptr(), qn, sc._idx32.data_ptr(), sc._d2.data_ptr(), cs, E.ALGO_STREAM), 5)
-        out["brute_force_probe"] = {"kernel": "nn_sample_bounds_kernel + brute2_prep_kernel + tile_reg_kernel<false> (expanded-form packed-fp32 filter, points in registers, exact fp64 recheck) + nn_reduce_candidates_kernel",
-                                    "queries": qn, "kernel_ms": ms, "queries_per_s": qn / (ms * 1e-3),
-                                    "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
-                                    "algorithmic_flops_per_s": 8 * qn * len(local_pts) / (ms * 1e-3)}
-        # the same batch as a radius count (kd_nearest_range + kd_res_size semantics) through the brute-force family
-        r4 = torch.full((qn,), 1.0, dtype=torch.float32, device=sc.device)
-        cnt4 = torch.empty(qn, dtype=torch.int32, device=sc.device)
-        ms = timed(lambda: sc.cloud.radius_count_device(q.data_ptr(), r4.data_ptr(), qn, cnt4.data_ptr(), cs, E.ALGO_STREAM), 5)
-        out["brute_force_count_probe"] = {"kernel": "brute2_prep_count_kernel + tile_reg_kernel<true> (same filter, exact fp64 test of what may lie inside the ball)",
-                                          "queries": qn, "radius": 1.0, "kernel_ms": ms, "pair_evals_per_s": qn * len(local_pts) / (ms * 1e-3),
-                                          "mean_count": float(cnt4.double().mean().item())}
-        del r4, cnt4
-        # (c) corridor side (config C3): sphere inflation of 200 seeds against the 10M-point cloud through the
-        # host-buffer entry point (PCIe and launch latency included) -- ms per pass
-        seeds = synth.uniform_points(4, 200, 10.0, 90.0).astype(np.float64)
-        prm = E.inflate_params((50.0, 50.0, 50.0), 1.0e9, 0.25, 1.5)
-        for _ in range(3):
-            sc.cloud.inflate(prm, seeds)
-        ts = []
-        for _ in range(20):
-            t1 = time.perf_counter()
-            sc.cloud.inflate(prm, seeds)
-            ts.append(1e3 * (time.perf_counter() - t1))
-        out["corridor_probe"] = {"what": "pct_inflate_batch, 200 seeds (seed 4), search_margin 0.25, max_radius 1.5, host buffers",
-                                 "ms_per_pass_median": float(np.median(ts)), "ms_per_pass_p99": float(np.percentile(ts, 99))}
-
-    if a.stream_probe and world == 1 and sc.cloud.has_grid:
-        # radius count through the index (kd_nearest_range + kd_res_size semantics, d2 <= r*r), same cloud and query batch
-        r1 = torch.full((Q,), 1.0, dtype=torch.float32, device=sc.device)
-        ts = []
-        for k in range(6):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            cnt = sc.radius_count(q, r1)
-            torch.cuda.synchronize()
-            if k:
-                ts.append(time.perf_counter() - t1)
-        out["radius_count_probe"] = {"what": f"pct_radius_count_batch_dev, {Q} queries, r = 1.0, cell-pruned cooperative kernel",
-                                     "ms_per_batch": 1e3 * float(np.median(ts)), "queries_per_s": Q / float(np.median(ts)),
-                                     "mean_count": float(cnt.double().mean().item())}
-        del r1, cnt
-
-    if a.stream_probe and world == 1:
-        # config C2: 1 M uniform points (seed 1), 4096 queries (seed 2), host buffers in and out (PCIe + launch latency included)
-        p2 = synth.uniform_points(1, 1_000_000, 0.0, 100.0)
-        q2 = synth.uniform_points(2, 4096, 0.0, 100.0)
-        with E.Cloud(len(p2)) as c2:
-            c2.set_input(p2)
-            def med(fn, n=7):
-                ts = []
-                for k in range(n):
-                    t1 = time.perf_counter()
-                    fn()
-                    if k:
-                        ts.append(1e3 * (time.perf_counter() - t1))
-                return float(np.median(ts))
-            brute_ms = med(lambda: c2.nn(q2, E.ALGO_STREAM))
-            build_ms = med(lambda: c2.build_grid(), 4)
-            grid_ms = med(lambda: c2.nn(q2, E.ALGO_GRID))
-        out["c2_probe"] = {"what": "C2: 1,000,000 uniform points, 4096 NN queries, host buffers (pct_nn_batch_algo)",
-                           "brute_force_ms": brute_ms, "pair_evals_per_s": 4096 * 1e6 / (brute_ms * 1e-3),
-                           "index_build_ms": build_ms, "indexed_ms": grid_ms, "indexed_queries_per_s": 4096 / (grid_ms * 1e-3)}
-
-    if world == 1 and algo == E.ALGO_GRID and a.stream_probe:
-        # the per-frame index build on the headline cloud (setInput's rebuild, corridor_finder.cpp:93-99): bounding box + two-level LDS
-        # counting sort into cells, points already resident in HBM; wall clock around pct_cloud_build_grid (it ends synchronised)
-        tb = []
-        for _ in range(6):
-            E.sync()
-            t1 = time.perf_counter()
-            sc.cloud.build_grid(a.cell)
-            tb.append(1e3 * (time.perf_counter() - t1))
-        bm = float(np.median(tb[1:]))
-        out["index_build_probe"] = {"what": f"pct_cloud_build_grid on the {len(local_pts)}-point cloud resident in HBM (bbox + gb_hist + gb_scatter + gb_cells)",
-                                    "ms_median": bm, "points_per_s": len(local_pts) / (bm * 1e-3)}
-
     if a.replan_probe and world == 1:
         out["replan_probe"] = replan_probe(E, synth)
-        # corridor generation per replan (config C1: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
-        # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches of 64 samples, one fused launch per batch
+        # corridor generation per replan (config C1 scenario: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
+        # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches, one fused launch per batch
         from pointcloudtraj_amd import corridor, scenarios
         cloud1 = scenarios.sensed_cloud(12.0)
         scenarios.timed_scenario(corridor.SafeRegionRrtStar(80000), cloud1)          # warm-up (first launches, allocations)
         out["corridor_replan_probe"] = dict(scenarios.timed_scenario(corridor.SafeRegionRrtStar(80000), cloud1),
                                             what="C1 corridor scenario: setInput + SafeRegionExpansion(1500) + Refine(400) + new frame + Evaluate + Refine(200)",
                                             cloud_points=int(len(cloud1)))
+        out["c1_stated_probe"] = c1_stated_probe(E, None)    # config C1 exactly as SURVEY 8(d) states it
 
     if a.replan_probe and world == 1:
         # ingest stage in front of the cloud: voxel de-duplication of the 10 M-point cloud at res 0.25
@@ -674,7 +802,6 @@ def main():
             vm.clear()
             n_vox = vm.add_device(d_pts.data_ptr(), len(local_pts), 12)
             ms.append(vm.last_ms())
-        t1 = time.perf_counter()
         again = vm.add_device(d_pts.data_ptr(), len(local_pts), 12)      # second pass: every point hits an existing voxel
         out["ingest_probe"] = {"what": "pct_voxel_map_add_dev: 10 M fp32 points resident in HBM -> first-seen voxel cloud, res 0.25",
                                "points": int(len(local_pts)), "voxels": int(n_vox), "kernels_ms": float(np.median(ms[1:])),
@@ -683,18 +810,22 @@ def main():
         vm.close()
         del d_pts
 
+    if a.clustered_probe and world == 1:
+        out["clustered_probe"] = clustered_probe(E, synth, torch, sc.device, Q)
+
     if a.c4_probe and world == 1:
         out["c4_probe"] = c4_probe(E, synth, torch, sc.device, Q)
 
+    O = None
     if a.cpu_queries > 0 and world == 1:
+        from oracle import oracle as O
         ncpu = a.cpu_points or a.points
-        base, cpu_idx, cq = cpu_baseline(lambda: local_pts[:ncpu], ncpu, q_host, min(a.cpu_queries, Q))
+        base, cpu_idx, cq = cpu_baseline(lambda: local_pts[:ncpu], ncpu, q_hosts[0], min(a.cpu_queries, Q))
         out["cpu_baseline"] = base
         if ncpu == a.points:     # same cloud: the GPU answers must equal the host kd-tree's (parity in the bench run itself)
             gi = idx_keep[:len(cq)].cpu().numpy()
             out["cpu_baseline"]["gpu_matches_cpu_indices"] = bool(np.array_equal(gi, cpu_idx))
         if "corridor_replan_probe" in out:   # the same corridor scenario on the CPU restatement (oracle/rrt_port.c + kd-tree port), one core
-            from oracle import oracle as O
             from pointcloudtraj_amd import scenarios
             cpu_cor = scenarios.timed_scenario(O.PortCorridor(), scenarios.sensed_cloud(12.0))
             out["cpu_baseline"]["corridor_replan_ms"] = cpu_cor["total_ms"]
@@ -706,6 +837,14 @@ def main():
                 out["cpu_baseline"]["voxel_ingest_points_per_s"] = 2_000_000 / (time.perf_counter() - t1)
             out["cpu_baseline"]["corridor_same_path_as_gpu"] = bool(cpu_cor["status"] == out["corridor_replan_probe"]["status"]
                                                                      and cpu_cor["path_len"] == out["corridor_replan_probe"]["path_len"])
+    if "c1_stated_probe" in out:
+        g = out["c1_stated_probe"]
+        gpath = g.pop("_path")
+        if O is not None:                                    # the CPU side only with the baseline leg
+            c = c1_stated_probe(E, O)
+            cpath = c.pop("_path")
+            c["same_corridor"] = bool(np.array_equal(cpath[0], gpath[0]) and np.array_equal(cpath[1], gpath[1]) and c.pop("status") == g["status"])
+            g["cpu_restatement"] = c
     print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()

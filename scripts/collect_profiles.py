@@ -29,7 +29,9 @@ for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2"):
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(fs[0])):
-        agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # the same kernel name covers very different launches (a 4096-query and a 1 M-query batch): one entry per (kernel, grid size)
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        agg[f'{name} @grid={r.get("Grid_Size", "?")}'][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         if "pct::" in k:
             pmc.setdefault(k, {}).update({c: {"mean_per_launch": sum(x) / len(x), "launches": len(x)} for c, x in v.items()})
