@@ -8,6 +8,14 @@
 // file (any channel would do: a ROS parameter, MPI, a socket), the other ranks wait for it.  Every rank then checks a sample of
 // the merged answers against a plain host loop over the WHOLE cloud in the same fp64 arithmetic.  Exit code 0 = all matched.
 // examples/run_shard_client.sh starts W ranks on W GPUs.  With W = 1 the collectives run on a one-rank communicator.
+// The same batch then goes through the ROUTED form (pct_shard_route_build / pct_shard_route_nn_dev: slab ownership, owned answers
+// exchanged as records) and must give the identical answers.
+//
+//     shard_client local <world> [total points] [queries] [halo spacings = 4]
+//
+// runs <world> ranks of the routed form inside this one process on one card (pct_shard_local_world: RCCL refuses two ranks on one
+// device) against a single cloud holding everything: identical answers required, plus the sizes of the slabs and how many answers
+// needed the second round.  A halo of 0 spacings forces that round for a good share of the batch.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -34,8 +42,78 @@ static float coord(uint64_t seed, uint64_t k) { return 200.0f * ((float)(mix(see
         if (st_ != PCT_OK) { std::fprintf(stderr, "rank %d: %s failed (%d): %s\n", rank, #call, st_, pct_last_error()); return 2; } \
     } while (0)
 
+#include <hip/hip_runtime_api.h>
+
+static int run_local(int world, int64_t N, int64_t Q, double halo)
+{
+    const int rank = -1;
+    CHECK(pct_init(0));
+    std::vector<float> all((size_t)3 * N), q((size_t)3 * Q);
+    for (size_t k = 0; k < all.size(); k++) all[k] = coord(6, k);
+    for (size_t k = 0; k < q.size(); k++) q[k] = coord(7, k);
+    // a few duplicated rows (exact ties across slabs must resolve to the lowest global index) and queries on top of points
+    for (int64_t k = 0; k < std::min<int64_t>(N / 2, 2000); k++) for (int d = 0; d < 3; d++) all[(size_t)3 * (N - 1 - k) + d] = all[(size_t)3 * (7 * k % (N / 2)) + d];
+    for (int64_t k = 0; k < std::min<int64_t>(Q / 4, 500); k++) for (int d = 0; d < 3; d++) q[(size_t)3 * k + d] = all[(size_t)3 * ((13 * k) % N) + d];
+    // the reference answer: one cloud holding everything
+    pct_cloud *whole = nullptr;
+    CHECK(pct_cloud_create(N, &whole));
+    CHECK(pct_cloud_upload_aos(whole, all.data(), N, 12));
+    CHECK(pct_cloud_build_grid(whole, 0.0f));
+    std::vector<uint32_t> want_i((size_t)Q), got_i((size_t)Q);
+    std::vector<double> want_d((size_t)Q), got_d((size_t)Q);
+    CHECK(pct_nn_batch_algo(whole, PCT_ALGO_GRID, q.data(), Q, want_i.data(), want_d.data()));
+    // W ranks in this process: contiguous index ranges in, slabs out
+    std::vector<pct_shard *> ranks((size_t)world);
+    CHECK(pct_shard_local_world(world, ranks.data()));
+    std::vector<const void *> lp((size_t)world);
+    std::vector<int64_t> ln((size_t)world), lb((size_t)world);
+    for (int r = 0; r < world; r++) {
+        int64_t b = 0, e = 0;
+        CHECK(pct_shard_range(ranks[(size_t)r], N, &b, &e));
+        lp[(size_t)r] = all.data() + 3 * b; ln[(size_t)r] = e - b; lb[(size_t)r] = b;
+    }
+    std::vector<pct_route *> routes((size_t)world);
+    CHECK(pct_shard_route_build_world(ranks.data(), world, lp.data(), ln.data(), 12, lb.data(), halo, routes.data()));
+    float *d_q = nullptr; uint32_t *d_i = nullptr; double *d_d = nullptr;
+    if (hipMalloc((void **)&d_q, sizeof(float) * 3 * Q) != hipSuccess || hipMalloc((void **)&d_i, sizeof(uint32_t) * Q * world) != hipSuccess ||
+        hipMalloc((void **)&d_d, sizeof(double) * Q * world) != hipSuccess) return 2;
+    if (hipMemcpy(d_q, q.data(), sizeof(float) * 3 * Q, hipMemcpyHostToDevice) != hipSuccess) return 2;
+    std::vector<uint32_t *> oi((size_t)world);
+    std::vector<double *> od((size_t)world);
+    for (int r = 0; r < world; r++) { oi[(size_t)r] = d_i + (size_t)r * Q; od[(size_t)r] = d_d + (size_t)r * Q; }
+    int bad = 0;
+    for (int rep = 0; rep < 2; rep++) {            // twice: the workspaces and counters of a second batch
+        CHECK(pct_shard_route_nn_world(routes.data(), world, d_q, Q, oi.data(), od.data(), nullptr));
+        if (hipDeviceSynchronize() != hipSuccess) return 2;
+        for (int r = 0; r < world; r++) {
+            if (hipMemcpy(got_i.data(), oi[(size_t)r], sizeof(uint32_t) * Q, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(got_d.data(), od[(size_t)r], sizeof(double) * Q, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+            for (int64_t k = 0; k < Q; k++)
+                if (got_i[(size_t)k] != want_i[(size_t)k] || got_d[(size_t)k] != want_d[(size_t)k]) {
+                    if (bad++ < 8) std::fprintf(stderr, "rank %d query %lld: routed (%u, %.17g) single cloud (%u, %.17g)\n", r, (long long)k, got_i[(size_t)k], got_d[(size_t)k], want_i[(size_t)k], want_d[(size_t)k]);
+                }
+        }
+    }
+    uint64_t owned_sum = 0, uncert = 0;
+    for (int r = 0; r < world; r++) {
+        int64_t sp = 0; uint64_t ow = 0, un = 0, ba = 0;
+        CHECK(pct_shard_route_stats(routes[(size_t)r], &sp, &ow, &un, &ba));
+        std::printf("local rank %d/%d: slab of %lld points, owned %llu of %lld queries per batch, %llu uncertified per batch\n", r, world, (long long)sp,
+                    (unsigned long long)(ow / ba), (long long)Q, (unsigned long long)(un / ba));
+        owned_sum += ow / ba; uncert = un / ba;
+    }
+    if ((int64_t)owned_sum != Q) { std::fprintf(stderr, "owned shares add up to %llu of %lld\n", (unsigned long long)owned_sum, (long long)Q); bad++; }
+    std::printf("routed form, %d ranks in one process, halo %.1f spacings: %lld queries, %llu in the second round, %d mismatches\n", world, halo, (long long)Q,
+                (unsigned long long)uncert, bad);
+    for (int r = 0; r < world; r++) { pct_shard_route_destroy(routes[(size_t)r]); pct_shard_destroy(ranks[(size_t)r]); }
+    (void)hipFree(d_q); (void)hipFree(d_i); (void)hipFree(d_d);
+    pct_cloud_destroy(whole);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 3 && std::strcmp(argv[1], "local") == 0)
+        return run_local(std::atoi(argv[2]), argc > 3 ? std::atoll(argv[3]) : 2000000, argc > 4 ? std::atoll(argv[4]) : 65536, argc > 5 ? std::atof(argv[5]) : 4.0);
     if (argc < 4) { std::fprintf(stderr, "usage: %s rank world rendezvous_file [points] [queries]\n", argv[0]); return 64; }
     const int rank = std::atoi(argv[1]), world = std::atoi(argv[2]);
     const std::string path = argv[3];
@@ -102,6 +180,32 @@ int main(int argc, char **argv)
         }
     }
     for (int64_t k = 0; k < Q; k++) if (idx[(size_t)k] != idx_b[(size_t)k] || d2[(size_t)k] != d2_b[(size_t)k]) bad++;
+    // the routed form over the same communicator: slabs instead of index ranges, the owned answers exchanged as records
+    {
+        pct_route *route = nullptr;
+        CHECK(pct_shard_route_build(sh, local.data(), e - b, 12, b, 4.0, &route));
+        float *d_q = nullptr; uint32_t *d_i = nullptr; double *d_d = nullptr;
+        if (hipMalloc((void **)&d_q, sizeof(float) * 3 * Q) != hipSuccess || hipMalloc((void **)&d_i, sizeof(uint32_t) * Q) != hipSuccess || hipMalloc((void **)&d_d, sizeof(double) * Q) != hipSuccess) return 2;
+        if (hipMemcpy(d_q, q.data(), sizeof(float) * 3 * Q, hipMemcpyHostToDevice) != hipSuccess) return 2;
+        CHECK(pct_shard_route_nn_dev(route, d_q, Q, d_i, d_d, nullptr));
+        if (hipDeviceSynchronize() != hipSuccess) return 2;
+        const auto r0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; r++) CHECK(pct_shard_route_nn_dev(route, d_q, Q, d_i, d_d, nullptr));
+        if (hipDeviceSynchronize() != hipSuccess) return 2;
+        const double rms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r0).count() / reps;
+        std::vector<uint32_t> ri((size_t)Q);
+        std::vector<double> rd((size_t)Q);
+        if (hipMemcpy(ri.data(), d_i, sizeof(uint32_t) * Q, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(rd.data(), d_d, sizeof(double) * Q, hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        int rbad = 0;
+        for (int64_t k = 0; k < Q; k++) if (ri[(size_t)k] != idx[(size_t)k] || rd[(size_t)k] != d2[(size_t)k]) rbad++;
+        int64_t sp = 0; uint64_t ow = 0, un = 0, ba = 0;
+        CHECK(pct_shard_route_stats(route, &sp, &ow, &un, &ba));
+        std::printf("rank %d/%d: routed form: slab of %lld points, %llu of %lld queries owned, %llu uncertified per batch, %.3f ms per batch (device buffers), %d mismatches vs index-range shards\n",
+                    rank, world, (long long)sp, (unsigned long long)(ow / ba), (long long)Q, (unsigned long long)(un / ba), rms, rbad);
+        bad += rbad;
+        pct_shard_route_destroy(route);
+        (void)hipFree(d_q); (void)hipFree(d_i); (void)hipFree(d_d);
+    }
     std::printf("rank %d/%d: shard [%lld, %lld) of %lld points, %lld queries merged in %.3f ms per batch (host buffers), %d mismatches\n", rank, world,
                 (long long)b, (long long)e, (long long)N, (long long)Q, ms, bad);
     pct_cloud_destroy(cloud);

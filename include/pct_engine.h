@@ -247,6 +247,18 @@ int pct_merge_mask_dev(const double *d_d2_local, const double *d_d2_best, const 
 /* behind the second reduction: merged int32 candidates -> u32 indices (INT32_MAX -> PCT_NO_INDEX).  include/pct_shard.h wraps the
  * whole exchange step (these two kernels + the RCCL calls) for C / C++ callers. */
 int pct_merge_finish_dev(const int32_t *d_cand, uint32_t *d_idx, int64_t Q, void *stream);
+/* ---- device helpers of the spatially routed multi-GPU form (include/pct_shard.h; the host logic lives in libpct_shard.so).
+ * cuts: world + 1 ascending slab boundaries along `axis` (cuts[0] = -inf, cuts[world] = +inf); an answer record is
+ * {uint32 query, uint32 global index, double d2} = 16 bytes, d2 < 0 = "not certified by its owner". ---- */
+int pct_cloud_upload_aos_dev(pct_cloud *c, const void *d_pts, int64_t n, int64_t stride_bytes);      /* setInput from device memory */
+int pct_route_owner_dev(const double *cuts, int world, int axis, int rank, const float *d_q, int64_t Q, uint32_t *d_counts /* [world] */,
+                        uint32_t *d_mine_ids, float *d_mine_q, void *stream);
+int pct_route_certify_dev(int axis, double lo_edge, double hi_edge, const float *d_mine_q, const uint32_t *d_mine_ids, int64_t m,
+                          const uint32_t *d_lidx, const double *d_ld2, const uint32_t *d_gid, void *d_answers, void *stream);
+int pct_route_scatter_dev(const void *d_answers, int64_t n, uint32_t *d_idx, double *d_d2, uint32_t *d_flag_count, uint32_t *d_flag_ids, void *stream);
+int pct_route_gather_queries_dev(const float *d_q, const uint32_t *d_ids, int64_t n, float *d_out, void *stream);
+int pct_route_to_global_dev(uint32_t *d_lidx, int64_t n, const uint32_t *d_gid, void *stream);
+int pct_route_put_back_dev(const uint32_t *d_ids, int64_t n, const uint32_t *d_idx, const double *d_d2, uint32_t *d_out_idx, double *d_out_d2, void *stream);
 /* make sure workspaces for batches up to Q exist (call before capturing a graph) */
 int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q);
 

@@ -56,6 +56,36 @@ int pct_shard_radius_count_dev(pct_shard *s, pct_cloud *local, int algo, const f
 /* host buffers, synchronous: upload the batch, run, download */
 int pct_shard_nn(pct_shard *s, pct_cloud *local, int algo, const float *q, int64_t Q, uint32_t *idx, double *d2);
 
+/* ---- Routed form: slab ownership (the N > 1 throughput path).
+ * Under index-range sharding every rank answers every query, and a cell-pruned query costs what the local point density makes it
+ * cost, whatever the shard's size: W ranks do W times the work.  pct_shard_route_build re-distributes the cloud ONCE into W slabs
+ * of equal point count along its longest axis (plus a halo of `halo_spacings` mean point spacings on both sides; rows keep their
+ * ascending global order), after which every query is answered by the one rank that owns its slab (1/W of the batch per rank), the
+ * owned answers are exchanged as 16-byte records {query, global index, d2} -- an all-gather of variable-sized slices: grouped
+ * ncclSend / ncclRecv over xGMI, Q x 16 B x (W-1)/W received per rank instead of two all-reduces over the whole batch -- and an
+ * answer the owner cannot certify (the point found is not strictly nearer than the edge of its halo) is answered by everybody in
+ * a second round merged like the index-range form.  Identical results to the single cloud (lowest global index on exact ties).
+ * The entry point synchronises `stream` twice per batch (the owned share sizes the next launch and the exchange; the
+ * number of uncertified answers decides whether there is a second round). ---- */
+typedef struct pct_route pct_route;
+/* collective over all ranks.  local_points: this rank's rows [index_begin, index_begin + n_local) of the global cloud, host memory,
+ * x,y,z fp32 at the start of every stride_bytes-byte record */
+int pct_shard_route_build(pct_shard *s, const void *local_points, int64_t n_local, int64_t stride_bytes, int64_t index_begin,
+                          double halo_spacings, pct_route **out);
+/* Q replicated queries (device, the same on every rank); every rank gets all Q answers */
+int pct_shard_route_nn_dev(pct_route *r, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
+int pct_shard_route_stats(const pct_route *r, int64_t *slab_points, uint64_t *owned, uint64_t *uncertified, uint64_t *batches);
+int pct_shard_route_destroy(pct_route *r);
+
+/* Several ranks in ONE process, on the process's one device: the same phases, the bytes moved between the ranks' buffers by plain
+ * copies instead of RCCL (which refuses two ranks on one device).  A rehearsal of W ranks on one card (tests), and the building
+ * block for a single process that keeps several slabs.  out: `world` handles, to be released with pct_shard_destroy. */
+int pct_shard_local_world(int world, pct_shard **out);
+int pct_shard_route_build_world(pct_shard *const *ranks, int world, const void *const *local_points, const int64_t *n_local, int64_t stride_bytes,
+                                const int64_t *index_begin, double halo_spacings, pct_route **out);
+/* d_idx[k] / d_d2[k]: rank k's result arrays (Q entries each; they may all be the same arrays) */
+int pct_shard_route_nn_world(pct_route *const *routes, int world, const float *d_q, int64_t Q, uint32_t *const *d_idx, double *const *d_d2, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,9 +89,11 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     client_src = os.path.join(ROOT, "examples", "shard_client.cpp")
     if os.path.exists(client_src) and os.path.exists(SHARD_SO) and (force or _stale(SHARD_CLIENT, [client_src, SHARD_SO, shard_hdr] + hdrs)):
         # the link line a planner node adds: -lpct_shard -lpct_engine (RCCL and the HIP runtime come in through libpct_shard.so)
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", SHARD_CLIENT, client_src,
+        # (the routed form takes device buffers: the client allocates them with the HIP runtime API, hence -I/opt/rocm/include -lamdhip64)
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-ffp-contract=off", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+               "-o", SHARD_CLIENT, client_src,
                "-L" + LIB, "-lpct_shard", "-lpct_engine", "-pthread", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link," + LIB,
-               "-L/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+               "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)

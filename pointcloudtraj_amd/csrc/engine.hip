@@ -2319,6 +2319,90 @@ int pct_merge_finish_dev(const int32_t *d_cand, uint32_t *d_idx, int64_t Q, void
     return PCT_OK;
 }
 
+// ---- device helpers of the routed multi-GPU form (include/pct_shard.h; host logic in csrc/shard.cpp) ----------------------------
+int pct_cloud_upload_aos_dev(pct_cloud *c, const void *d_pts, int64_t n, int64_t stride_bytes)
+{
+    if (!c || n < 0 || (n > 0 && !d_pts) || stride_bytes < 12 || (stride_bytes & 3)) return fail(PCT_ERR_INVALID, "bad upload arguments");
+    if (n > c->cap) return fail(PCT_ERR_CAPACITY, "%lld points > capacity %lld", (long long)n, (long long)c->cap);
+    if (c->host_mapped) return fail(PCT_ERR_INVALID, "small (host-mapped) clouds are filled from host buffers");
+    drop_grid(c);
+    if (n) {
+        deinterleave_kernel<<<ceil_div(n, 256), 256, 0, g_stream>>>(static_cast<const unsigned char *>(d_pts), (uint32_t)stride_bytes, (uint32_t)n, c->x, c->y, c->z, 0u);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g_stream));
+    }
+    c->count = n;
+    c->ring_next = n % std::max<int64_t>(c->cap, 1);
+    return after_replace(c);
+}
+
+static int route_cuts(const double *cuts, int world, int axis, RouteCuts *C)
+{
+    if (!cuts || world < 1 || world > kRouteMaxWorld || axis < 0 || axis > 2) return fail(PCT_ERR_INVALID, "bad slab description (at most %d ranks)", kRouteMaxWorld);
+    C->world = world; C->axis = axis;
+    for (int k = 0; k <= world; k++) C->cut[k] = cuts[k];
+    return PCT_OK;
+}
+
+int pct_route_owner_dev(const double *cuts, int world, int axis, int rank, const float *d_q, int64_t Q, uint32_t *d_counts, uint32_t *d_mine_ids,
+                        float *d_mine_q, void *stream)
+{
+    if (Q < 0 || rank < 0 || rank >= world || (Q > 0 && (!d_q || !d_counts || !d_mine_ids || !d_mine_q))) return fail(PCT_ERR_INVALID, "bad route_owner arguments");
+    RouteCuts C{};
+    PCTCHK(route_cuts(cuts, world, axis, &C));
+    PCTCHK(require_init());
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * (size_t)world, s));
+    if (Q) route_owner_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(C, rank, d_q, (uint32_t)Q, d_counts, d_mine_ids, d_mine_q);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_certify_dev(int axis, double lo_edge, double hi_edge, const float *d_mine_q, const uint32_t *d_mine_ids, int64_t m, const uint32_t *d_lidx,
+                          const double *d_ld2, const uint32_t *d_gid, void *d_answers, void *stream)
+{
+    if (m < 0 || axis < 0 || axis > 2 || (m > 0 && (!d_mine_q || !d_mine_ids || !d_lidx || !d_ld2 || !d_gid || !d_answers))) return fail(PCT_ERR_INVALID, "bad route_certify arguments");
+    if (m == 0) return PCT_OK;
+    route_certify_kernel<<<ceil_div(m, 256), 256, 0, (hipStream_t)stream>>>(axis, lo_edge, hi_edge, d_mine_q, d_mine_ids, (uint32_t)m, d_lidx, d_ld2, d_gid,
+                                                                             static_cast<RouteAnswer *>(d_answers));
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_scatter_dev(const void *d_answers, int64_t n, uint32_t *d_idx, double *d_d2, uint32_t *d_flag_count, uint32_t *d_flag_ids, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_answers || !d_idx || !d_d2 || !d_flag_count || !d_flag_ids))) return fail(PCT_ERR_INVALID, "bad route_scatter arguments");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_flag_count, 0, sizeof(uint32_t), s));
+    if (n) route_scatter_kernel<<<ceil_div(n, 256), 256, 0, s>>>(static_cast<const RouteAnswer *>(d_answers), (uint32_t)n, d_idx, d_d2, d_flag_count, d_flag_ids);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_gather_queries_dev(const float *d_q, const uint32_t *d_ids, int64_t n, float *d_out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_q || !d_ids || !d_out))) return fail(PCT_ERR_INVALID, "bad route_gather arguments");
+    if (n) route_gather_queries_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(d_q, d_ids, (uint32_t)n, d_out);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_to_global_dev(uint32_t *d_lidx, int64_t n, const uint32_t *d_gid, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_lidx || !d_gid))) return fail(PCT_ERR_INVALID, "bad route_to_global arguments");
+    if (n) route_to_global_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(d_lidx, (uint32_t)n, d_gid);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_put_back_dev(const uint32_t *d_ids, int64_t n, const uint32_t *d_idx, const double *d_d2, uint32_t *d_out_idx, double *d_out_d2, void *stream)
+{
+    if (n < 0 || (n > 0 && (!d_ids || !d_idx || !d_d2 || !d_out_idx || !d_out_d2))) return fail(PCT_ERR_INVALID, "bad route_put_back arguments");
+    if (n) route_put_back_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)stream>>>(d_ids, (uint32_t)n, d_idx, d_d2, d_out_idx, d_out_d2);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
 int pct_set_timing(pct_cloud *c, int level)
 {
     if (!c || level < 0 || level > 2) return fail(PCT_ERR_INVALID, "timing level must be 0, 1 or 2");

@@ -547,6 +547,105 @@ __global__ __launch_bounds__(256) void merge_mask_kernel(const double *__restric
     cand[i] = (d == d2_best[i] && d < __builtin_huge_val() && ix <= 0x7FFFFFFEu) ? (int32_t)ix : 0x7FFFFFFF;
 }
 
+// ---- spatially routed multi-GPU queries (include/pct_shard.h, "routed form"): every rank owns a slab of the cloud along one axis
+// and answers only the queries that fall into it.  An answer travels as one 16-byte record.
+struct RouteAnswer { uint32_t query, gid; double d2; };        // d2 < 0: the owner could not certify it (everybody answers it again)
+constexpr int kRouteMaxWorld = 64;
+struct RouteCuts { int world, axis; double cut[kRouteMaxWorld + 1]; };       // slab k = [cut[k], cut[k+1]) along `axis`; cut[0] = -inf, cut[world] = +inf
+
+__device__ __forceinline__ int route_owner(const RouteCuts &C, double x)
+{
+    int k = 0;
+    for (int j = 1; j < C.world; j++) k += x >= C.cut[j] ? 1 : 0;             // cuts ascend: the number of cuts at or below x
+    return k;
+}
+
+// owner of every query; counts per owner (one LDS histogram per block); the queries of `rank` are compacted (any order: an answer
+// carries its query's index)
+__global__ __launch_bounds__(256) void route_owner_kernel(RouteCuts C, int rank, const float *__restrict__ q, uint32_t Q,
+                                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ mine_ids, float *__restrict__ mine_q)
+{
+    __shared__ uint32_t h[kRouteMaxWorld];
+    __shared__ uint32_t s_base;
+    if (threadIdx.x < (uint32_t)kRouteMaxWorld) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int own = -1;
+    float qx = 0, qy = 0, qz = 0;
+    uint32_t slot = 0;
+    if (i < Q) {
+        qx = q[3 * i]; qy = q[3 * i + 1]; qz = q[3 * i + 2];
+        own = route_owner(C, (double)(C.axis == 0 ? qx : C.axis == 1 ? qy : qz));
+        slot = atomicAdd(&h[own], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)C.world && h[threadIdx.x]) {
+        const uint32_t b = atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+        if ((int)threadIdx.x == rank) s_base = b;
+    }
+    __syncthreads();
+    if (own == rank) {
+        const uint32_t p = s_base + slot;
+        mine_ids[p] = i;
+        mine_q[3 * p] = qx; mine_q[3 * p + 1] = qy; mine_q[3 * p + 2] = qz;
+    }
+}
+
+// the owner's answers as records: certified when the point found is STRICTLY nearer than the edge of the slab's halo (a point just
+// outside the halo at exactly that distance could tie with a lower index), otherwise flagged with d2 = -1
+__global__ __launch_bounds__(256) void route_certify_kernel(int axis, double lo_edge, double hi_edge, const float *__restrict__ mine_q,
+                                                            const uint32_t *__restrict__ mine_ids, uint32_t m, const uint32_t *__restrict__ lidx,
+                                                            const double *__restrict__ ld2, const uint32_t *__restrict__ gid,
+                                                            RouteAnswer *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double x = (double)mine_q[3 * i + axis];
+    const double margin = fmin(x - lo_edge, hi_edge - x);             // +inf at the outer slabs' outer sides
+    const double d2 = ld2[i];
+    const bool found = lidx[i] != kNoIndex;
+    const bool cert = found && margin > 0.0 && d2 < margin * margin;
+    RouteAnswer a;
+    a.query = mine_ids[i];
+    a.gid = cert ? gid[lidx[i]] : kNoIndex;
+    a.d2 = cert ? d2 : -1.0;
+    out[i] = a;
+}
+
+// records -> the result arrays (each query appears exactly once); flagged queries are counted and listed
+__global__ __launch_bounds__(256) void route_scatter_kernel(const RouteAnswer *__restrict__ rec, uint32_t n, uint32_t *__restrict__ out_idx,
+                                                            double *__restrict__ out_d2, uint32_t *__restrict__ flag_count, uint32_t *__restrict__ flag_ids)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RouteAnswer a = rec[i];
+    out_idx[a.query] = a.gid;
+    out_d2[a.query] = a.d2;
+    if (a.d2 < 0.0) flag_ids[atomicAdd(flag_count, 1u)] = a.query;
+}
+
+// second round: gather the flagged queries / map local answers to global ids / put the merged answers back
+__global__ __launch_bounds__(256) void route_gather_queries_kernel(const float *__restrict__ q, const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = ids[i];
+    out[3 * i] = q[3 * k]; out[3 * i + 1] = q[3 * k + 1]; out[3 * i + 2] = q[3 * k + 2];
+}
+__global__ __launch_bounds__(256) void route_to_global_kernel(uint32_t *__restrict__ lidx, uint32_t n, const uint32_t *__restrict__ gid)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && lidx[i] != kNoIndex) lidx[i] = gid[lidx[i]];
+}
+__global__ __launch_bounds__(256) void route_put_back_kernel(const uint32_t *__restrict__ ids, uint32_t n, const uint32_t *__restrict__ idx, const double *__restrict__ d2,
+                                                             uint32_t *__restrict__ out_idx, double *__restrict__ out_d2)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_idx[ids[i]] = idx[i];
+    out_d2[ids[i]] = d2[i];
+}
+
 // behind the second reduction: the merged int32 candidates back to the engine's index convention (INT32_MAX = no shard holds a point)
 __global__ __launch_bounds__(256) void merge_finish_kernel(const int32_t *__restrict__ cand, uint32_t *__restrict__ idx, uint32_t Q)
 {

@@ -129,3 +129,20 @@ def test_cpp_shard_client_over_rccl():
     r = subprocess.run(["bash", os.path.join(ROOT, "examples", "run_shard_client.sh"), "1", "3000000", "2048"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("world,halo", [(2, 4.0), (3, 4.0), (8, 4.0), (3, 0.0)])
+def test_routed_form_in_the_c_abi_equals_the_single_cloud(world, halo):
+    """include/pct_shard.h routed form (slab ownership: pct_shard_route_build_world / pct_shard_route_nn_world) with 2, 3 and 8 ranks in
+    ONE process on the box's one card (RCCL refuses two ranks on one device; the phases are the same, the bytes are moved by copies):
+    every rank's answers must equal the single cloud's -- indices and fp64 distances, duplicated rows across slabs (lowest global
+    index) and queries on top of points included.  halo 0 forces the second round (everybody answers what the owner cannot
+    certify) for a good share of the batch."""
+    import subprocess
+    from pointcloudtraj_amd import build
+    r = subprocess.run([build.SHARD_CLIENT, "local", str(world), "1500000", "40000", str(halo)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " 0 mismatches" in r.stdout, r.stdout
+    last = r.stdout.strip().splitlines()[-1]
+    second = int(last.split(" in the second round")[0].split()[-1])
+    assert (second > 100) if halo == 0.0 else (second < 400), last
