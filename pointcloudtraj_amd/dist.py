@@ -375,7 +375,7 @@ class SpatialShardedCloud:
             lo_edge, hi_edge = self.cuts[self.rank] - self.halo, self.cuts[self.rank + 1] + self.halo
             margin = torch.minimum(x - lo_edge if np.isfinite(lo_edge) else torch.full_like(x, inf),
                                    hi_edge - x if np.isfinite(hi_edge) else torch.full_like(x, inf))
-            cert = valid & (margin > 0) & (ld <= margin * margin)
+            cert = valid & (margin > 0) & (ld < margin * margin)       # strictly: a point just outside the halo at exactly that distance could tie with a lower index
             d2[mine] = torch.where(cert, ld, torch.full_like(ld, -1.0))     # -1 = "ask everybody": it wins the min-reduction
             gi[mine] = torch.where(cert, g, torch.full_like(g, _I64_MAX))
             self.stats["owned"] += int(mine.numel())

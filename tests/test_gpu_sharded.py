@@ -146,3 +146,40 @@ def test_routed_form_in_the_c_abi_equals_the_single_cloud(world, halo):
     last = r.stdout.strip().splitlines()[-1]
     second = int(last.split(" in the second round")[0].split()[-1])
     assert (second > 100) if halo == 0.0 else (second < 400), last
+
+
+def test_routed_c_abi_inside_a_torch_distributed_process():
+    """bench.py --gpus N drives the routed form of libpct_shard.so from a torch.distributed rank: the library's own RCCL communicator
+    next to torch's, the rendezvous token broadcast through torch.distributed, device buffers owned by torch.  One rank here (one
+    card): the communicator, the slab build (collectives on a one-rank communicator) and the routed batch must work in that process
+    and equal the plain cloud's answers."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PCT_ROOT"])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dist.init_process_group("nccl", rank=0, world_size=1)
+torch.cuda.set_device(0)
+t = torch.ones(4, device="cuda"); dist.all_reduce(t)
+from pointcloudtraj_amd import engine as E, shard as SH, synth
+E.init(0)
+pts = synth.uniform_points(11, 600_000, 0, 80); q = synth.uniform_points(12, 50_000, -2, 82)
+tok = torch.zeros(SH.ID_BYTES, dtype=torch.uint8, device="cuda")
+tok.copy_(torch.frombuffer(bytearray(SH.unique_id()), dtype=torch.uint8)); dist.broadcast(tok, src=0)
+sh = SH.Shard(bytes(tok.cpu().numpy().tobytes()), 0, 1, 0)
+route = sh.route(pts, 0, 4.0)
+dq = torch.from_numpy(q).cuda(); di = torch.empty(len(q), dtype=torch.int32, device="cuda"); dd = torch.empty(len(q), dtype=torch.float64, device="cuda")
+for _ in range(2):
+    route.nn_device(dq.data_ptr(), len(q), di.data_ptr(), dd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+c = E.Cloud(len(pts)); c.set_input(pts); c.build_grid()
+wi, wd = c.nn(q, E.ALGO_GRID)
+ok = np.array_equal(di.cpu().numpy().view(np.uint32), wi) and np.array_equal(dd.cpu().numpy(), wd)
+print("stats", route.stats(), "equal", ok)
+route.close(); sh.close(); c.close(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+    env = dict(os.environ, PCT_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "equal True" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
