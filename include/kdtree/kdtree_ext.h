@@ -17,6 +17,12 @@
 extern "C" {
 #endif
 
+/* Single-query dispatch of kd_nearest* / kd_nearest_range*: node sets of up to `nodes` nodes are answered from the host copy of the
+ * node list (BASELINE.json config C1: "CPU Utils/kdtree path (plumbing, no GPU)" -- a launch costs ~11 us, the reference's walk
+ * under one), larger ones by the HIP kernels; same arithmetic, same tie winner, same range order either way (the tests run every
+ * fixture both ways).  Default 4096 (environment PCT_KD_HOST_MAX); 0 = always the device; negative = back to the default. */
+void kdx_set_host_threshold(int64_t nodes);
+int64_t kdx_host_threshold(void);
 int kdx_size(struct kdtree *tree);
 void *kdx_node_data(struct kdtree *tree, int32_t node);
 /* stored (fp64) position of a node; returns 0 on success */

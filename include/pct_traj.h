@@ -62,6 +62,10 @@ int pct_traj_nearest_voxels(const pct_traj_wire *w, double twirl_len, pct_voxel_
  * when n == 1, comes from the first two control points.  Host arithmetic (atan2), n values out. */
 int pct_traj_end_yaws(const double *path_x, const double *path_y, int64_t n, const double *coef_x, const double *coef_y, double *end_yaws);
 
+/* test hook: the two device-side statements of "n choose k" (Pascal's rule of the trajectory evaluators, the multiplicative
+ * recurrence of the collision-check kernels) as 13 x 13 tables of doubles, 0 above the diagonal */
+int pct_debug_binomials(double *pascal, double *recurrence);
+
 #ifdef __cplusplus
 }
 #endif

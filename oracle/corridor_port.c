@@ -79,6 +79,8 @@ static double ocor_binom(int n, int k)
     return floor(c + 0.5);
 }
 
+double ocor_binom_public(int n, int k) { return ocor_binom(n, k); }
+
 /*
  * src/sim_planning_demo.cpp:715-727.  coef is row `seg` of PolyCoeff, laid out
  * [x_0..x_n, y_0..y_n, z_0..z_n] with that segment's own n

@@ -24,6 +24,11 @@ static int factorial_from(int n, int k)
     return a;
 }
 static int binom_int(int n, int k) { return factorial_from(n, k + 1) / factorial_from(n - k, 2); }
+/* the three ways this oracle writes "n choose k" (pinned against the reference's compiled table, tests/golden/binomials.npz):
+ * out3 = { binomial_coefs' integer form, bezier_base's double form (traj_port), the same in corridor_port } */
+double ocor_binom_public(int n, int k);
+static double binom_d(int n, int k);
+void otraj_binomials(int n, int k, double *out3) { out3[0] = (double)binom_int(n, k); out3[1] = binom_d(n, k); out3[2] = ocor_binom_public(n, k); }
 
 /* bezier_base.cpp:256-266: C(k) = combinatorial(n, k), C_v over n-1, C_a over n-2, held as doubles */
 static double binom_d(int n, int k)

@@ -181,6 +181,47 @@ int32_t reference_tie_winner(const kdtree *t, const double *q, const uint32_t *t
     return win;
 }
 
+// ---- small node sets: the host answers ------------------------------------------------------------------------------------------
+// The planner's RRT* tree holds tens to a few thousand spheres and asks ONE question at a time (corridor_finder.cpp:428-437, 464):
+// a launch plus the bus round trip is ~11 us whatever the tree's size, the reference's own walk well under one.  BASELINE.json
+// states this use as config C1, "CPU Utils/kdtree path (plumbing, no GPU)".  Up to PCT_KD_HOST_MAX nodes (default 4096; 0 = always
+// the device) the single-query calls below therefore scan the host copy of the node list -- the same fp64 arithmetic
+// ((dx^2 + dy^2) + dz^2 on the stored doubles, this file is built with -ffp-contract=off), the same tie rule (reference_tie_winner)
+// and the same range order (build_range_result) as the device path, which the tests run on the same fixtures with the threshold at
+// 0.  The node set still lives in host-mapped memory for the kernels that read it (the fused expansion batch, kdx_*), the obstacle
+// cloud is never answered here, and kd_create still refuses to run without a device: this is a size dispatch, not a fallback.
+int64_t g_host_max = -1;              // -1: not read yet
+int64_t host_max_nodes()
+{
+    if (g_host_max < 0) { const char *e = std::getenv("PCT_KD_HOST_MAX"); g_host_max = e ? std::max<int64_t>(std::atoll(e), 0) : 4096; }
+    return g_host_max;
+}
+
+inline double node_d2(const kdtree *t, int64_t i, const double *q)      // kdtree.c:379-382
+{
+    const double dx = t->pos[3 * (size_t)i] - q[0], dy = t->pos[3 * (size_t)i + 1] - q[1], dz = t->pos[3 * (size_t)i + 2] - q[2];
+    double s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+int32_t host_nearest(const kdtree *t, const double *q)
+{
+    const int64_t n = t->count();
+    double best = node_d2(t, 0, q);
+    int64_t bi = 0, ties = 1;
+    for (int64_t i = 1; i < n; i++) {
+        const double d = node_d2(t, i, q);
+        if (d < best) { best = d; bi = i; ties = 1; }
+        else if (d == best) ties++;
+    }
+    if (ties == 1) return (int32_t)bi;
+    std::vector<uint32_t> tied;
+    for (int64_t i = 0; i < n; i++) if (node_d2(t, i, q) == best) tied.push_back((uint32_t)i);
+    return reference_tie_winner(t, q, tied.data(), (int64_t)tied.size());
+}
+
 }  // namespace
 
 extern "C" {
@@ -275,6 +316,14 @@ int kd_insert3f(struct kdtree *t, float x, float y, float z, void *data)
 struct kdres *kd_nearest(struct kdtree *t, const double *q)
 {
     if (!t || t->count() == 0) return nullptr;
+    if (t->count() <= host_max_nodes()) {                 // small node set: scanned on the host (see host_max_nodes)
+        kdres *r = new (std::nothrow) kdres();
+        if (!r) return nullptr;
+        r->tree = t;
+        r->items.push_back(host_nearest(t, q));
+        r->size = 1;
+        return r;
+    }
     if (sync_device(t)) return nullptr;
     uint32_t idx = PCT_NO_INDEX, ties = 0;
     double d2 = 0;
@@ -318,6 +367,14 @@ struct kdres *kd_nearest_range(struct kdtree *t, const double *q, double range)
     r->tree = t;
     const int64_t n = t->count();
     if (n == 0) return r;
+    if (n <= host_max_nodes()) {                          // small node set: the in-range nodes from a host scan, then the same replay
+        std::vector<uint32_t> hits;
+        const double r2 = range * range;                  // kdtree.c:273: dist_sq <= SQ(range)
+        for (int64_t i = 0; i < n; i++) if (node_d2(t, i, q) <= r2) hits.push_back((uint32_t)i);
+        kdres *out = build_range_result(t, q, range, hits.data(), (int64_t)hits.size());
+        delete r;
+        return out;
+    }
     if (sync_device(t)) { delete r; return nullptr; }
     std::vector<uint32_t> hits((size_t)n);
     int64_t nh = 0;
@@ -395,6 +452,9 @@ void *kd_res_item3f(struct kdres *r, float *x, float *y, float *z)
 void *kd_res_item_data(struct kdres *r) { return kd_res_item(r, nullptr); }
 
 // ---- batch extensions (include/kdtree/kdtree_ext.h) ---------------------------------------------------------
+// node sets up to `nodes` answer single queries from the host copy (0 = always the device; negative = back to PCT_KD_HOST_MAX / 4096)
+void kdx_set_host_threshold(int64_t nodes) { g_host_max = nodes; }
+int64_t kdx_host_threshold(void) { return host_max_nodes(); }
 int kdx_size(struct kdtree *t) { return t ? (int)t->count() : 0; }
 void *kdx_node_data(struct kdtree *t, int32_t node) { return (t && node >= 0 && node < t->count()) ? t->data[node] : nullptr; }
 int kdx_node_pos(struct kdtree *t, int32_t node, double pos[3])

@@ -10,6 +10,8 @@
 
 #pragma clang fp contract(off)
 
+#include "bernstein.hpp"
+
 namespace pct {
 
 constexpr int kWave = 64;
@@ -2578,11 +2580,10 @@ __global__ __launch_bounds__(256) void bezier_samples_kernel(BezierDesc B, doubl
         const double *c = B.coef + (size_t)seg * B.row_stride;
         // binomials as exact doubles (bezier_base.cpp:33-48 computes them with integer factorials)
         double binom[kMaxBezierOrder + 1];
-        binom[0] = 1.0;
-        for (int j = 1; j <= order; j++) binom[j] = floor(binom[j - 1] * (double)(order - j + 1) / (double)j + 0.5);
+        for (int j = 0; j <= order; j++) binom[j] = bernstein_binom(order, j);
         for (int d = 0; d < 3; d++) {
             double acc = 0.0;
-            for (int j = 0; j < m; j++) acc += binom[j] * c[d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+            for (int j = 0; j < m; j++) acc += binom[j] * c[d * m + j] * pow_uint_cr(u, j) * pow_uint_cr(1.0 - u, order - j);
             pos[3 * s + d] = acc * T;
         }
     }
@@ -2611,9 +2612,8 @@ __global__ __launch_bounds__(256) void bezier_block_kernel(GridDesc G0, const fl
     const double u = sample_t[slot] / T;
     if ((int)threadIdx.x < 3 * m) {
         const int d = (int)threadIdx.x / m, j = (int)threadIdx.x % m;
-        double b = 1.0;                                            // bezier_base.cpp:33-48 binomials as exact doubles
-        for (int i = 1; i <= j; i++) b = floor(b * (double)(order - i + 1) / (double)i + 0.5);
-        s_term[d * m + j] = b * coef[(size_t)seg * row_stride + d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+        const double b = bernstein_binom(order, j);
+        s_term[d * m + j] = b * coef[(size_t)seg * row_stride + d * m + j] * pow_uint_cr(u, j) * pow_uint_cr(1.0 - u, order - j);
     }
     __syncthreads();
     if (threadIdx.x < 3) {
@@ -2657,11 +2657,10 @@ __global__ __launch_bounds__(128) void bezier_eval_kernel(const double *__restri
     const double u = sample_t[s] / T;
     const double *c = coef + (size_t)seg * row_stride;
     double binom[kMaxBezierOrder + 1];
-    binom[0] = 1.0;
-    for (int j = 1; j <= order; j++) binom[j] = floor(binom[j - 1] * (double)(order - j + 1) / (double)j + 0.5);
+    for (int j = 0; j <= order; j++) binom[j] = bernstein_binom(order, j);
     for (int d = 0; d < 3; d++) {
         double acc = 0.0;
-        for (int j = 0; j < m; j++) acc += binom[j] * c[d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+        for (int j = 0; j < m; j++) acc += binom[j] * c[d * m + j] * pow_uint_cr(u, j) * pow_uint_cr(1.0 - u, order - j);
         pos_dev[3 * s + d] = acc * T;
         pos_mapped[3 * s + d] = acc * T;
     }

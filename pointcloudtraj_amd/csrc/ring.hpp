@@ -399,9 +399,8 @@ __global__ __launch_bounds__(256) void replan_block_kernel(RingView V, GridDesc 
         const double u = f64a[H.off_sample_t + s] / T;
         if ((int)threadIdx.x < 3 * m) {
             const int d = (int)threadIdx.x / m, j = (int)threadIdx.x % m;
-            double b = 1.0;                                            // bezier_base.cpp:33-48 binomials as exact doubles
-            for (int i = 1; i <= j; i++) b = floor(b * (double)(order - i + 1) / (double)i + 0.5);
-            s_term[d * m + j] = b * f64a[H.off_coef + (size_t)seg * H.row_stride + d * m + j] * pow(u, (double)j) * pow(1.0 - u, (double)(order - j));
+            const double b = bernstein_binom(order, j);
+            s_term[d * m + j] = b * f64a[H.off_coef + (size_t)seg * H.row_stride + d * m + j] * pow_uint_cr(u, j) * pow_uint_cr(1.0 - u, order - j);
         }
         __syncthreads();
         if (threadIdx.x < 3) {

@@ -13,6 +13,7 @@
 
 #include "../../include/pct_traj.h"
 #include "engine_internal.hpp"
+#include "bernstein.hpp"
 
 using pct_internal::fail;
 
@@ -42,6 +43,16 @@ __host__ __device__ inline double binom(int n, int k)
     return (double)row[k];
 }
 
+// test hook: both ways the device writes "n choose k", for every 0 <= k <= n <= 12
+__global__ void binomial_tables_kernel(double *__restrict__ pascal, double *__restrict__ recurrence)
+{
+    const int n = (int)threadIdx.x / 13, k = (int)threadIdx.x % 13;
+    if (n < 13) {
+        pascal[n * 13 + k] = k <= n ? binom(n, k) : 0.0;
+        recurrence[n * 13 + k] = k <= n ? pct::bernstein_binom(n, k) : 0.0;
+    }
+}
+
 // getStateFromBezier (sim_planning_demo.cpp:688-713).  ctrl = row seg of PolyCoeff: [x_0..x_n, y_0..y_n, z_0..z_n].
 __global__ __launch_bounds__(256) void bezier_state_kernel(const double *__restrict__ polycoef, int64_t row_stride,
                                                            const int32_t *__restrict__ orders, const int32_t *__restrict__ seg,
@@ -58,13 +69,13 @@ __global__ __launch_bounds__(256) void bezier_state_kernel(const double *__restr
     for (int d = 0; d < 3; d++) {
         double p = 0.0, v = 0.0, a = 0.0;
         for (int j = 0; j < m; j++) {
-            const double tj = pow(t, (double)j);
-            p += C[j] * ctrl[d * m + j] * tj * pow(1.0 - t, (double)(order - j));
+            const double tj = pct::pow_uint_cr(t, j);
+            p += C[j] * ctrl[d * m + j] * tj * pct::pow_uint_cr(1.0 - t, order - j);
             if (j < m - 1)
-                v += Cv[j] * (double)order * (ctrl[d * m + j + 1] - ctrl[d * m + j]) * tj * pow(1.0 - t, (double)(order - j - 1));
+                v += Cv[j] * (double)order * (ctrl[d * m + j + 1] - ctrl[d * m + j]) * tj * pct::pow_uint_cr(1.0 - t, order - j - 1);
             if (j < m - 2)
                 a += Ca[j] * (double)order * (double)(order - 1) * (ctrl[d * m + j + 2] - 2.0 * ctrl[d * m + j + 1] + ctrl[d * m + j]) * tj *
-                     pow(1.0 - t, (double)(order - j - 2));
+                     pct::pow_uint_cr(1.0 - t, order - j - 2);
         }
         state9[9 * i + d] = p;
         state9[9 * i + 3 + d] = v;
@@ -88,7 +99,7 @@ __global__ __launch_bounds__(256) void wire_sample_kernel(const double *__restri
     const double T = time[s];
     double px = 0.0, py = 0.0, pz = 0.0;
     for (int k = 0; k <= n; k++) {
-        const double c = binom(n, k), a = pow(t, (double)k), b = pow(1.0 - t, (double)(n - k));
+        const double c = binom(n, k), a = pct::pow_uint_cr(t, k), b = pct::pow_uint_cr(1.0 - t, n - k);
         px += T * cx[sh + k] * c * a * b;
         py += T * cy[sh + k] * c * a * b;
         pz += T * cz[sh + k] * c * a * b;
@@ -318,6 +329,20 @@ int pct_traj_end_yaws(const double *path_x, const double *path_y, int64_t n, con
             end_yaws[i] = std::sqrt(vx * vx + vy * vy) > 0.01 ? std::atan2(vy, vx) : 10.0;
         }
     }
+    return PCT_OK;
+}
+
+int pct_debug_binomials(double *pascal, double *recurrence)
+{
+    if (!pascal || !recurrence) return fail(PCT_ERR_INVALID, "null output");
+    double *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, sizeof(double) * 2 * 169));
+    binomial_tables_kernel<<<1, 192>>>(d, d + 169);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(pascal, d, sizeof(double) * 169, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(recurrence, d + 169, sizeof(double) * 169, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PCT_ERR_HIP, "binomial tables: %s", hipGetErrorString(e));
     return PCT_OK;
 }
 

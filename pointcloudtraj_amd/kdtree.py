@@ -52,8 +52,19 @@ def lib():
         L.kd_res_item3.argtypes = [vp, dp, dp, dp]
         L.kd_res_item3f.argtypes = [vp, fp, fp, fp]
         L.kd_res_item_data.argtypes = [vp]
+        L.kdx_set_host_threshold.argtypes = [C.c_int64]
+        L.kdx_host_threshold.restype = C.c_int64
         _lib = L
     return _lib
+
+
+def set_host_threshold(nodes: int):
+    """node sets of up to `nodes` nodes answer single queries on the host (0 = always the device; negative = the default)"""
+    lib().kdx_set_host_threshold(int(nodes))
+
+
+def host_threshold() -> int:
+    return int(lib().kdx_host_threshold())
 
 
 class KDTree:

@@ -9,6 +9,9 @@ What is recorded, and from which implementation:
       outputs of the REFERENCE's own Utils/kdtree/src/kdtree.c (compiled unmodified into
       oracle/_ref/libkdtree_ref.so) driven through its public kd_* API.  These pin the
       oracle port (tests/test_oracle_golden.py) and, on the GPU, the HIP path.
+  binomials.npz
+      the 13 x 13 table c(n, k) of the REFERENCE's own Planner/src/binomial_coefs.cpp (the one planner source that compiles
+      stand-alone; oracle/_ref/libbinomial_ref.so).  Pins the three ways the oracle and the two ways the device write "n choose k".
   inflate_c1.npz, bezier_check.npz
       outputs of oracle/corridor_port.c (planner arithmetic: parity UNPINNED, see that
       file's header) on top of the pinned NN.  Every NN inside them is cross-checked
@@ -295,9 +298,21 @@ def gen_bezier():
     P.close()
 
 
+def gen_binomials():
+    print("binomial table of the reference's Planner/src/binomial_coefs.cpp (compiled into oracle/_ref/libbinomial_ref.so):")
+    L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libbinomial_ref.so"))
+    tab = np.zeros((13, 13), np.int32)
+    L.refbinom_table(tab.ctypes.data_as(C.c_void_p))
+    save("binomials.npz", c_n_k=tab)
+
+
 if __name__ == "__main__":
     O.build(force=True)
     assert O.have_ref(), "needs /root/reference to build oracle/_ref"
+    if len(sys.argv) > 1 and sys.argv[1] == "binomials":      # only the table (the other fixtures stay as committed)
+        gen_binomials()
+        sys.exit(0)
+    gen_binomials()
     gen_nn()
     gen_range()
     gen_api_edges()

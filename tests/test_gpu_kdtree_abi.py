@@ -10,11 +10,16 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def K():
+@pytest.fixture(scope="module", params=["device", "host_below_4096"])
+def K(request):
+    """every test of this file runs twice: with every single query answered by the HIP kernels (threshold 0), and with the default
+    dispatch -- node sets of up to 4096 nodes scanned on the host (kdtree_ext.h kdx_set_host_threshold; BASELINE config C1), larger
+    ones on the device.  Same fixtures, same required answers."""
     from pointcloudtraj_amd import engine, kdtree
     engine.init(0)
-    return kdtree
+    kdtree.set_host_threshold(0 if request.param == "device" else 4096)
+    yield kdtree
+    kdtree.set_host_threshold(-1)
 
 
 @pytest.mark.parametrize("name", ["kd_nn_n1.npz", "kd_nn_n2.npz", "kd_nn_n17.npz", "kd_nn_n1000.npz",

@@ -122,35 +122,88 @@ def test_inflate_empty_cloud(E):
     c.close()
 
 
+def _bezier_samples_exact_powers(polycoef, seg_time, orders, t_start, stop, dt=0.02):
+    """checkSafeTrajectory's sample enumeration (sim_planning_demo.cpp:735-771) and getPosFromBezier (:715-727) restated in Python
+    floats (IEEE doubles, one rounding per operation: the same arithmetic as the C restatement) with the Bernstein powers taken
+    EXACTLY (rational arithmetic) and rounded once.  Returns (positions, per-sample flag "libm's pow gave the correctly rounded
+    power for every term")."""
+    import math
+    from fractions import Fraction
+    T, nseg = [float(v) for v in seg_time], len(seg_time)
+    t_s, first = float(t_start), 0
+    for first in range(nseg):
+        if t_s > T[first] and first + 1 < nseg:
+            t_s -= T[first]
+        else:
+            break
+    pos, libm_exact = [], []
+    acc, done = 0.0, False
+    for sgm in range(first, nseg):
+        t = t_s if sgm == first else 0.0
+        while t < T[sgm]:
+            acc += dt
+            if acc > stop:
+                done = True
+                break
+            n = int(orders[sgm]); m = n + 1; u = t / T[sgm]
+            ok, p = True, []
+            for d in range(3):
+                a = 0.0
+                for j in range(m):
+                    pu, pv = float(Fraction(u) ** j), float(Fraction(1.0 - u) ** (n - j))
+                    ok = ok and pu == math.pow(u, j) and pv == math.pow(1.0 - u, n - j)
+                    a += float(math.comb(n, j)) * float(polycoef[sgm, d * m + j]) * pu * pv
+                p.append(a * T[sgm])
+            pos.append(p); libm_exact.append(ok)
+            t += dt
+        if done:
+            break
+    return np.asarray(pos, np.float64).reshape(-1, 3), np.asarray(libm_exact, bool)
+
+
 @pytest.mark.parametrize("grid", [False, True])
 def test_bezier_golden(E, grid):
-    """Sample enumeration and first-hit index must match the oracle exactly; positions come from
-    device pow() and are held to 1e-12 relative (libm vs ocml pow may differ in the last ulp);
-    squared distances to the north star's 1e-6 relative; NN indices exactly wherever the sample
-    position is bit-identical."""
+    """The sampled collision check against the fixture (oracle/corridor_port.c over the pinned NN): sample enumeration and first-hit
+    index exactly, and EVERY sample position pinned bit for bit: the device evaluates the Bernstein powers correctly rounded
+    (csrc/bernstein.hpp pow_uint_cr; ocml's pow left 5-10 % of the samples an ulp away in round 2), so its positions equal the
+    formula with exactly rounded powers on 100 % of the samples, and that equals the fixture (libm's pow) wherever glibc's pow is
+    itself correctly rounded -- all but one of the fixture's samples (case 8, sample 31: pow(0.4588235294117644, 3) comes back one
+    ulp low from glibc).  With the positions, squared distances, NN indices and radii are bit-exact too."""
     g = load_golden("bezier_check.npz")
     c = make_cloud(E, g["points"], grid=grid)
     prm = E.inflate_params(g["start"], float(g["sample_range"]), float(g["search_margin"]), float(g["max_radius"]))
+    total = off_libm = 0
     for i in range(int(g["n_cases"])):
         r = c.bezier_check(prm, g[f"case{i}_polycoef"], g["seg_time"], g["orders"], float(g[f"case{i}_t_start"]),
                            float(g[f"case{i}_stop_time"]))
         want_pos = g[f"case{i}_pos"]
         assert r["n"] == len(want_pos)
-        np.testing.assert_allclose(r["pos"], want_pos, rtol=1e-12, atol=1e-12)
-        np.testing.assert_allclose(r["d2"], g[f"case{i}_d2"], rtol=1e-6)
-        np.testing.assert_allclose(r["radius"], g[f"case{i}_radius"], rtol=1e-6, atol=1e-9)
-        assert r["first_hit"] == int(g[f"case{i}_first_hit"])
-        same = np.all(r["pos"].astype(np.float32) == want_pos.astype(np.float32), axis=1)
-        assert same.mean() > 0.9
-        assert np.array_equal(r["d2"][same], g[f"case{i}_d2"][same])
+        exact_pos, libm_ok = _bezier_samples_exact_powers(g[f"case{i}_polycoef"], g["seg_time"], g["orders"], float(g[f"case{i}_t_start"]), float(g[f"case{i}_stop_time"]))
+        assert len(exact_pos) == len(want_pos)
+        assert np.array_equal(r["pos"], exact_pos), f"case {i}: device positions != the formula with exactly rounded powers"
+        assert np.array_equal(exact_pos[libm_ok], want_pos[libm_ok]), f"case {i}: fixture != formula where libm's pow is exact"
+        same = np.all(r["pos"].astype(np.float32) == want_pos.astype(np.float32), axis=1)      # what the NN sees is the fp32-narrowed point
+        assert np.all(same | ~libm_ok)
+        assert np.array_equal(r["d2"][same], g[f"case{i}_d2"][same]) and np.array_equal(r["radius"][same], g[f"case{i}_radius"][same])
         assert np.array_equal(r["idx"][same].astype(np.int64), np.where(g[f"case{i}_idx"][same] < 0, np.int64(E.NO_INDEX), g[f"case{i}_idx"][same].astype(np.int64)))
-        # the collision decision is pinned on every sample: where the fp32-narrowed position is bit-identical the radius is
-        # too; where device pow and libm pow differ in the last ulp the radius must be far enough from zero (1e-6) that the
-        # difference cannot flip it -- so first_hit can never sit on, or behind, a sample decided on unpinned input
-        want_rad = g[f"case{i}_radius"]
-        assert np.array_equal(r["radius"][same], want_rad[same])
-        assert np.all(np.abs(want_rad[~same]) > 1e-6) and np.array_equal(r["radius"] < 0, want_rad < 0)
+        assert np.array_equal(r["radius"] < 0, g[f"case{i}_radius"] < 0) and r["first_hit"] == int(g[f"case{i}_first_hit"])
+        total += len(want_pos)
+        off_libm += int(np.any(r["pos"] != want_pos, axis=1).sum())
+    assert total > 500 and off_libm <= 2, (total, off_libm)       # 759 samples, 8 with some libm power an ulp off, 1 whose position shows it
     c.close()
+
+
+def test_device_binomials_equal_the_reference_table():
+    """tests/golden/binomials.npz = the table of the reference's own Planner/src/binomial_coefs.cpp, compiled (oracle/_ref): both
+    device-side statements of n choose k (Pascal's rule in traj.hip, the recurrence of csrc/bernstein.hpp) must equal it for every
+    0 <= k <= n <= 12"""
+    import ctypes as C
+    from pointcloudtraj_amd import engine
+    tab = load_golden("binomials.npz")["c_n_k"].astype(np.float64)
+    a, b = np.zeros((13, 13)), np.zeros((13, 13))
+    engine._chk(engine.lib().pct_debug_binomials(C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data)))
+    lower = np.tril(np.ones((13, 13), bool))
+    assert np.array_equal(a[lower], tab[lower]) and np.array_equal(b[lower], tab[lower])
 
 
 def test_stream_vs_grid_vs_oracle_seeded(E, oracle):

@@ -146,6 +146,25 @@ def test_bezier_endpoint_interpolation(oracle):
         assert np.array_equal(b, row[[m - 1, 2 * m - 1, 3 * m - 1]])
 
 
+def test_binomials_of_the_restatement_equal_the_reference_table(oracle):
+    """Planner/src/binomial_coefs.cpp compiles stand-alone; its 13 x 13 table (tests/golden/binomials.npz, generated from
+    oracle/_ref/libbinomial_ref.so) pins the three ways the CPU restatement writes n choose k: the integer-factorial form of
+    traj_port.c (binomial_coefs.cpp:3-17, exact copy of the arithmetic, garbage above the diagonal included) and the two
+    double-valued recurrences standing for bezier_base.cpp:256-266 (traj_port.c, corridor_port.c)."""
+    import ctypes as C
+    tab = load_golden("binomials.npz")["c_n_k"]
+    assert tab[12, 6] == 924 and tab[8, 3] == 56 and np.array_equal(tab[4, :5], [1, 4, 6, 4, 1])
+    L = oracle.port_lib()
+    L.otraj_binomials.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    out = (C.c_double * 3)()
+    for n in range(13):
+        for k in range(13):
+            L.otraj_binomials(n, k, out)
+            assert out[0] == tab[n, k], (n, k)                   # the integer form: the whole table, as the reference computes it
+            if k <= n:
+                assert out[1] == tab[n, k] and out[2] == tab[n, k], (n, k)
+
+
 def test_pillar_map_known_answers():
     """Survey-time known answers for the restated map generator."""
     m = synth.pillar_map()
