@@ -14,7 +14,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "lib")
-ENGINE_SO = os.path.join(LIB, "libpct_engine.so")
+ENGINE_SO = os.environ.get("PCT_ENGINE_SO") or os.path.join(LIB, "libpct_engine.so")     # PCT_ENGINE_SO: an A/B build of the engine (scripts/ab_build.sh)
 KDTREE_SO = os.path.join(LIB, "libkdtree.so")
 DEMO_BIN = os.path.join(LIB, "seam_demo")
 NODE_BIN = os.path.join(LIB, "node_call_sites")

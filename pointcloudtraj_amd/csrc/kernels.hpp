@@ -1508,6 +1508,37 @@ __global__ __launch_bounds__(256) void nn_grid_kernel(GridDesc G, const float4 *
 // -------------------------------------------------------------------------------------
 constexpr int kCoop = 8;
 
+// Cross-lane traffic inside a group of 8 lanes goes through DPP (data-parallel primitives: the operand of a VALU instruction is read
+// from another lane of the same row) instead of ds_bpermute (an LDS instruction with its issue slot, ~50+ cycles of latency and an
+// lgkmcnt wait): the folds below sit on every query's critical path.
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1, 0, 3, 2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2, 3, 0, 1]
+constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside every 8 lanes: pairs the two quads of a group
+constexpr int kDppQuadBcast0 = 0x00, kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xAA, kDppQuadBcast3 = 0xFF;    // quad_perm [k, k, k, k]
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+#ifdef PCT_AB_NO_DPP        // A/B switch (scripts/ab_build.sh): the same data movement through ds_bpermute
+    const int lane = (int)(threadIdx.x & 63u), l8 = lane & 7, q = lane & 3;
+    const int src = CTRL == kDppXor1 ? (lane ^ 1) : CTRL == kDppXor2 ? (lane ^ 2) : CTRL == kDppHalfMirror ? ((lane & ~7) | (7 - l8)) :
+                    (lane - q + (CTRL == kDppQuadBcast0 ? 0 : CTRL == kDppQuadBcast1 ? 1 : CTRL == kDppQuadBcast2 ? 2 : 3));
+    return (uint32_t)__shfl((int)v, src, kWave);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+#endif
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return __longlong_as_double((long long)(((uint64_t)dpp_u32<CTRL>((uint32_t)(b >> 32)) << 32) | dpp_u32<CTRL>((uint32_t)b)));
+}
+
+// (measured on the dense batch kernel: the DPP form of the folds below costs registers -- 64 VGPRs + 16 bytes of scratch at 8 waves per
+// SIMD -- and the kernel ran 0.131 instead of 0.122 ms; with 7 waves per SIMD 0.128.  They stay on ds_bpermute; the pyramid walk,
+// which has registers to spare, uses the DPP forms: 1.06 against 1.09 ms.  gpurun_out logs r3_ab_dpp*.)
 __device__ __forceinline__ void coop_argmin8(double &d, uint32_t &i)
 {
 #pragma unroll
@@ -1906,7 +1937,10 @@ __device__ __forceinline__ void coop_finish_shells(const GridDesc &G, const floa
 }
 
 template <bool COUNT, bool WAVE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
+#ifndef PCT_AB_COOP_WAVES
+#define PCT_AB_COOP_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_COOP_WAVES, 8))) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                            const uint32_t *__restrict__ cell_start,
                                                            const float *__restrict__ q, uint32_t Q, uint32_t index_base,
                                                            const float4 *__restrict__ qsorted,

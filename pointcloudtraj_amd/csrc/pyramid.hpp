@@ -128,16 +128,7 @@ __global__ __launch_bounds__(256) void pyr_hint_kernel(GridDesc G, PyrDesc PD, c
     hint[c] = (unsigned char)L;
 }
 
-// ---- cross-lane helpers for a group of 8 lanes: DPP instead of ds_bpermute (no LDS round trip) ----------------------------------
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-constexpr int kDppXor1 = 0xB1;         // quad_perm [1, 0, 3, 2]
-constexpr int kDppXor2 = 0x4E;         // quad_perm [2, 3, 0, 1]
-constexpr int kDppHalfMirror = 0x141;  // lane i <-> 7 - i inside every 8 lanes: pairs the two quads of a group
-
+// ---- cross-lane helpers for a group of 8 lanes (DPP: kernels.hpp dpp_u32 and the kDpp* patterns) ----
 // minimum over the 8 lanes of a group, in all 8 lanes
 __device__ __forceinline__ uint32_t group8_min_u32(uint32_t v)
 {
@@ -513,8 +504,8 @@ __device__ __forceinline__ void pyr_answer(const GridDesc &G, const PyrDesc &PD,
         const uint32_t a = cell_start[row + xa], b = cell_start[row + xb + 1];
         const uint32_t my_s = a, my_e = ok ? b : a;
         if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
+        rs[0] = dpp_u32<kDppQuadBcast0>(my_s); rs[1] = dpp_u32<kDppQuadBcast1>(my_s); rs[2] = dpp_u32<kDppQuadBcast2>(my_s); rs[3] = dpp_u32<kDppQuadBcast3>(my_s);
+        re[0] = dpp_u32<kDppQuadBcast0>(my_e); re[1] = dpp_u32<kDppQuadBcast1>(my_e); re[2] = dpp_u32<kDppQuadBcast2>(my_e); re[3] = dpp_u32<kDppQuadBcast3>(my_e);
     }
     double bd = __builtin_huge_val();
     uint32_t bi = kNoIndex;
