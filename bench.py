@@ -102,7 +102,8 @@ def clustered_probe(E, synth, torch, device, Q, steps=10):
             for mode in (("pyramid", None),) + ((("shell_walk", "0"),) if len(pts) < 1_000_000 else ()):
                 if mode[1] is not None:
                     os.environ["PCT_PYRAMID"] = mode[1]
-                t0 = time.perf_counter()
+                c.build_grid()                                    # a sensor cloud is rebuilt every frame (corridor_finder.cpp:93-99): the timed
+                t0 = time.perf_counter()                           # build is the steady-state one (a sparse cloud's second build halves the cells)
                 c.build_grid()
                 E.sync()
                 t_build = 1e3 * (time.perf_counter() - t0)

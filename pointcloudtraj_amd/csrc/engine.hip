@@ -146,6 +146,7 @@ struct pct_cloud {
     unsigned char *pyr_hint = nullptr;          // start level of the walk per level-0 cell
     size_t pyr_cap = 0, pyr_total = 0, pyr_hint_cap = 0;
     double empty_frac = 0.0;
+    bool was_sparse = false;                    // the previous build found most cells empty: this one uses smaller cells
     // grid
     bool has_grid = false;
     GridDesc G{};
@@ -529,7 +530,7 @@ int build_pyramid(pct_cloud *c, const GridDesc &G)
     if (const char *e = std::getenv("PCT_PYRAMID")) mode = std::atoi(e);
     double min_empty = 0.25;                      // uniform cloud at 6 points per cell: e^-6 = 0.25 % of the cells are empty
     if (const char *e = std::getenv("PCT_PYRAMID_MIN_EMPTY")) min_empty = std::atof(e);
-    if (mode == 0 || (mode < 0 && c->empty_frac < min_empty)) return PCT_OK;
+    if (mode == 0 || (mode < 0 && c->empty_frac < min_empty)) { c->was_sparse = false; return PCT_OK; }
     PyrDesc P{};
     int nlev = 1;
     while (pyr_dim(G.gx, nlev - 1) > 2 || pyr_dim(G.gy, nlev - 1) > 2 || pyr_dim(G.gz, nlev - 1) > 2) nlev++;
@@ -565,6 +566,7 @@ int build_pyramid(pct_cloud *c, const GridDesc &G)
     c->P = P;
     c->pyr_total = total;
     c->has_pyr = true;
+    c->was_sparse = c->empty_frac > 0.6;
     return PCT_OK;
 }
 
@@ -1545,6 +1547,11 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
         // the block then decides 99 % of the queries (a wave needs all 8 of its queries decided to skip the cube);
         // same-box A/B on the 10 M uniform cloud: ppc 2 + cube first 0.169 ms, ppc 6 + block first 0.134 ms per 1 M queries
         double ppc = 6.0;
+        // a cloud that carried the pyramid at its previous build (surfaces, clusters: most cells empty) is rebuilt with cells of
+        // half the volume: the walk then scans 52 instead of 89 points per query for one more node visit (10 M pillar surfaces:
+        // 0.99 -> 1.10e9 q/s, scripts/probe_pyr.py with PCT_GRID_PPC 3 / 4 / 6 / 9 / 12).  The per-frame rebuild of a sensor cloud
+        // (corridor_finder.cpp:93-99) sees the same kind of cloud frame after frame, so the first build's verdict serves the next.
+        if (c->was_sparse) ppc = 3.0;
         if (const char *e = std::getenv("PCT_GRID_PPC")) ppc = std::max(0.05, std::atof(e));
         const double diag = std::max({ ext[0], ext[1], ext[2], 1e-6 });
         double vol = 1.0;

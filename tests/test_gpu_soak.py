@@ -75,6 +75,18 @@ def test_randomised_paths_agree():
         c.build_grid()
         _check_cell_index(c, pts)                 # every record in the cell its coordinates map to, cell_start a prefix sum
         i3, d3 = c.nn(q, E.ALGO_GRID)
+        # the same batch through the bounding-box pyramid, forced on whatever the occupancy (pyramid.hpp: fp32 walk + exact walk for
+        # its near-ties) -- and once more on the rebuilt index (a cloud found sparse halves its cells at the next build)
+        os.environ["PCT_PYRAMID"] = "1"
+        try:
+            for rebuild in range(2):
+                c.build_grid()
+                assert c.pyramid_info()["levels"] > 0
+                ip, dp = c.nn(q, E.ALGO_GRID)
+                assert np.array_equal(dp, d1) and np.array_equal(ip, i1), name + f" pyramid walk (build {rebuild})"
+        finally:
+            del os.environ["PCT_PYRAMID"]
+        c.build_grid()
         cg = c.radius_count(q[:2000], rad[:2000], E.ALGO_GRID)
         assert np.array_equal(d1, d2) and np.array_equal(i1, i2), name + " filter vs all-fp64"
         assert np.array_equal(d1, d3) and np.array_equal(i1, i3), name + " brute force vs cell-pruned"
