@@ -559,8 +559,11 @@ __device__ __forceinline__ void pyr_commit_work(uint32_t npts, uint32_t nruns, u
     }
 }
 
+#ifndef PCT_AB_PYR_WAVES
+#define PCT_AB_PYR_WAVES 6      // VALU-issue-bound: 6 waves per SIMD with up to 80 VGPRs beat 7-8 with 64-72 (1.17 vs 1.11e9 q/s on the 10 M pillar cloud)
+#endif
 template <bool COUNT, bool FAST>
-__global__ __launch_bounds__(256) void nn_grid_pyr_kernel(GridDesc G, PyrDesc PD, const PyrNode *__restrict__ nodes, const unsigned char *__restrict__ hint,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_PYR_WAVES, 8))) void nn_grid_pyr_kernel(GridDesc G, PyrDesc PD, const PyrNode *__restrict__ nodes, const unsigned char *__restrict__ hint,
                                                           const float4 *__restrict__ pts,
                                                           const uint32_t *__restrict__ cell_start, const float *__restrict__ q, uint32_t Q,
                                                           uint32_t index_base, const float4 *__restrict__ qsorted, uint32_t *__restrict__ out_idx,
