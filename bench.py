@@ -724,14 +724,36 @@ def main():
             t = torch.tensor([r_elapsed], dtype=torch.float64, device=sc.device)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
             r_elapsed = float(t.item())
+            # PARTITIONED batches (weak scaling): every rank brings its own batches; the queries travel to their owners, the answers back
+            route.nn_partitioned_device(q.data_ptr(), Q, r_idx.data_ptr(), r_d2.data_ptr(), cs_r)        # same batch on every rank: comparable
+            barrier()
+            same_p = bool(torch.equal(r_d2, d2_keep) and torch.equal(r_idx, idx_keep.to(torch.int32)))
+            own = [torch.from_numpy(synth.uniform_points(sd + 10007 * (rank + 1), Q, 0.0, side)).to(sc.device) for sd in QUERY_SEEDS]
+            for k in range(a.warmup):
+                route.nn_partitioned_device(own[k % len(own)].data_ptr(), Q, r_idx.data_ptr(), r_d2.data_ptr(), cs_r)
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(a.steps):
+                route.nn_partitioned_device(own[k % len(own)].data_ptr(), Q, r_idx.data_ptr(), r_d2.data_ptr(), cs_r)
+            barrier()
+            p_elapsed = time.perf_counter() - t1
+            t = torch.tensor([p_elapsed], dtype=torch.float64, device=sc.device)
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            p_elapsed = float(t.item())
+            del own
             st_r = route.stats()
+            partitioned = {"what": "partitioned batches in the C ABI (pct_shard_route_nn_partitioned_dev): every rank brings its OWN batch of Q queries per step "
+                                   "(distinct seeds per rank and step), the queries travel to the rank that owns their slab and the answers travel back (two "
+                                   "variable-sized all-to-alls of 16 bytes per query); the job answers world x Q queries per step (weak scaling)",
+                           "elapsed_s": p_elapsed, "ms_per_step": 1e3 * p_elapsed / a.steps, "queries_per_step_whole_job": world * Q,
+                           "answers_per_s_whole_job": world * Q * a.steps / p_elapsed, "same_answers_as_index_range_shards_on_a_common_batch": same_p}
             routed = {"what": "routed form in the C ABI (pct_shard_route_build / pct_shard_route_nn_dev): slabs of equal point count along the longest axis + halo "
                               "of 4 spacings, every query answered by the rank that owns its slab, owned answers exchanged as 16-byte records (grouped "
                               "ncclSend / ncclRecv), uncertified answers in a second round",
                       "elapsed_s": r_elapsed, "ms_per_step": 1e3 * r_elapsed / a.steps, "merged_answers_per_s": Q * a.steps / r_elapsed,
                       "redistribution_s": round(t_route, 3), "slab_points_rank0": st_r["slab_points"],
                       "owned_queries_rank0_per_batch": st_r["owned"] / max(st_r["batches"], 1), "uncertified_per_batch": st_r["uncertified"] / max(st_r["batches"], 1),
-                      "same_answers_as_index_range_shards": same_r}
+                      "same_answers_as_index_range_shards": same_r, "partitioned": partitioned}
             route.close()
             shd.close()
         except Exception as ex:      # noqa: BLE001  (the index-range figure then stays the headline)
@@ -775,13 +797,19 @@ def main():
         cnt, cnt_src, traffic = {}, None, None       # the committed PMC passes are of the N = 1 command
     bound, bound_detail = bound_from_counters(cnt)
     value = Q / elapsed * a.steps                    # merged answers per second (never multiplied by the rank count)
+    scaling_kind = "strong" if c4 else "weak"
     index_range = None
     if c4:
         index_range = {"what": "index-range shards (SURVEY 8e's partition): every rank answers the whole replicated batch on its contiguous index range, "
                                "all_reduce(min) on d2 then on the matching indices; the cost of a cell-pruned query does not shrink with the shard, so this "
                                "form stays near one GPU's rate", "ms_per_step": ms_per_step, "merged_answers_per_s": value}
-        if routed and "error" not in routed and routed.get("same_answers_as_index_range_shards"):
-            value = routed["merged_answers_per_s"]       # the headline at N > 1: the form whose per-rank work shrinks with N
+        part = routed.get("partitioned") if routed and "error" not in routed else None
+        if part and part["same_answers_as_index_range_shards_on_a_common_batch"]:
+            value = part["answers_per_s_whole_job"]      # the headline at N > 1: every rank its own queries (weak scaling), nothing replicated
+            ms_per_step = part["ms_per_step"]
+            scaling_kind = "weak"
+        elif routed and "error" not in routed and routed.get("same_answers_as_index_range_shards"):
+            value = routed["merged_answers_per_s"]       # replicated queries, every query answered by ONE rank
             ms_per_step = routed["ms_per_step"]
         elif spatial and "error" not in spatial and spatial.get("same_answers_as_index_range_shards") and spatial["merged_answers_per_s"] > value:
             value = spatial["merged_answers_per_s"]      # rehearsal (gloo): the same routing through torch.distributed
@@ -795,15 +823,16 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if c4 else "weak",
+        "scaling": scaling_kind,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": (f"C4: ONE cloud of {n_total} uniform fp32 points in [0,{side:.0f})^3 (seed 6) sharded by contiguous index range over {world} "
                          f"GPU(s) ({sc.end - sc.begin} points on rank 0), {Q} uniform NN queries per step ({len(qs)} distinct batches in rotation, seeds "
-                         f"{list(QUERY_SEEDS)}) replicated; value = merged answers/s of the ROUTED form (slab ownership, every query answered by one rank; config.headline_form), the "
-                         f"index-range form ({a.algo} kernel per shard + all_reduce(min) merge) beside it in index_range_shards"
+                         f"{list(QUERY_SEEDS)}) per rank; value = answers/s of the whole job in the form config.headline_form names (partitioned batches through the routed C ABI: every "
+                         f"rank brings its own batch, weak scaling; the replicated-batch routed form and the index-range form -- {a.algo} kernel per shard + "
+                         f"all_reduce(min) merge -- beside it in routed_c_abi / index_range_shards)"
                          if c4 else
                          f"C3-throughput: {a.points} uniform fp32 points in [0,{side:.1f})^3 (seed 3), {Q} uniform NN queries per step "
                          f"({len(qs)} distinct batches in rotation, seeds {list(QUERY_SEEDS)}), {a.algo} kernel, inputs resident in HBM"),
@@ -839,7 +868,9 @@ def main():
         out["index_range_shards"] = index_range
     if routed:
         out["routed_c_abi"] = routed
-        out["config"]["headline_form"] = ("routed (slab ownership, C ABI over RCCL)" if value == routed.get("merged_answers_per_s") else
+        out["config"]["headline_form"] = ("partitioned batches through the routed C ABI over RCCL: every rank its own Q queries per step (weak scaling)"
+                                          if scaling_kind == "weak" and c4 else
+                                          "routed (slab ownership, C ABI over RCCL), replicated batch" if value == routed.get("merged_answers_per_s") else
                                           "routed through torch.distributed (rehearsal)" if spatial and value == spatial.get("merged_answers_per_s") else "index-range shards")
     if c4_legs:
         out["c4_q4096"] = c4_legs

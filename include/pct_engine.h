@@ -253,6 +253,10 @@ int pct_merge_finish_dev(const int32_t *d_cand, uint32_t *d_idx, int64_t Q, void
 int pct_cloud_upload_aos_dev(pct_cloud *c, const void *d_pts, int64_t n, int64_t stride_bytes);      /* setInput from device memory */
 int pct_route_owner_dev(const double *cuts, int world, int axis, int rank, const float *d_q, int64_t Q, uint32_t *d_counts /* [world] */,
                         uint32_t *d_mine_ids, float *d_mine_q, void *stream);
+/* partitioned batches (every rank brings its own queries): owner + counts per owner, then the queries grouped by owner with their slots */
+int pct_route_owner_all_dev(const double *cuts, int world, int axis, const float *d_q, int64_t Q, uint32_t *d_counts /* [world] */, unsigned char *d_owner, void *stream);
+int pct_route_partition_dev(const uint32_t *offsets /* host, [world] */, int world, const unsigned char *d_owner, const float *d_q, int64_t Q,
+                            uint32_t *d_cursors /* [world] */, float *d_out_xyz, uint32_t *d_out_slot, void *stream);
 int pct_route_certify_dev(int axis, double lo_edge, double hi_edge, const float *d_mine_q, const uint32_t *d_mine_ids, int64_t m,
                           const uint32_t *d_lidx, const double *d_ld2, const uint32_t *d_gid, void *d_answers, void *stream);
 int pct_route_scatter_dev(const void *d_answers, int64_t n, uint32_t *d_idx, double *d_d2, uint32_t *d_flag_count, uint32_t *d_flag_ids, void *stream);

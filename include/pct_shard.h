@@ -77,6 +77,12 @@ int pct_shard_route_nn_dev(pct_route *r, const float *d_q, int64_t Q, uint32_t *
 int pct_shard_route_stats(const pct_route *r, int64_t *slab_points, uint64_t *owned, uint64_t *uncertified, uint64_t *batches);
 int pct_shard_route_destroy(pct_route *r);
 
+/* PARTITIONED batches: every rank brings its OWN Q queries (Q may differ per rank) and gets its own Q answers; the queries travel to the
+ * rank that owns their slab and the answers travel back (two variable-sized all-to-alls of 16 bytes per query, grouped ncclSend /
+ * ncclRecv); nothing is replicated and nobody answers a query twice -- weak scaling: the job answers the sum of all batches per step.
+ * Uncertified answers of all ranks are gathered and answered by everybody in a second round.  Collective; three stream synchronises. */
+int pct_shard_route_nn_partitioned_dev(pct_route *r, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream);
+
 /* Several ranks in ONE process, on the process's one device: the same phases, the bytes moved between the ranks' buffers by plain
  * copies instead of RCCL (which refuses two ranks on one device).  A rehearsal of W ranks on one card (tests), and the building
  * block for a single process that keeps several slabs.  out: `world` handles, to be released with pct_shard_destroy. */
@@ -85,6 +91,10 @@ int pct_shard_route_build_world(pct_shard *const *ranks, int world, const void *
                                 const int64_t *index_begin, double halo_spacings, pct_route **out);
 /* d_idx[k] / d_d2[k]: rank k's result arrays (Q entries each; they may all be the same arrays) */
 int pct_shard_route_nn_world(pct_route *const *routes, int world, const float *d_q, int64_t Q, uint32_t *const *d_idx, double *const *d_d2, void *stream);
+
+/* partitioned batches with every rank in this process: d_q[k] / Q[k] = rank k's own batch, d_idx[k] / d_d2[k] = its Q[k] answers */
+int pct_shard_route_nn_partitioned_world(pct_route *const *routes, int world, const float *const *d_q, const int64_t *Q, uint32_t *const *d_idx,
+                                         double *const *d_d2, void *stream);
 
 #ifdef __cplusplus
 }

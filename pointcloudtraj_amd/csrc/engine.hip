@@ -1473,7 +1473,7 @@ int pct_cloud_reserve_queries(pct_cloud *c, int64_t Q)
     PCTCHK(dev_alloc(&c->d_inv, q));
     PCTCHK(dev_alloc(&c->d_sres_idx, q));
     PCTCHK(dev_alloc(&c->d_sres_d2, q));
-    PCTCHK(dev_alloc(&c->d_todo, q + 16));
+    PCTCHK(dev_alloc(&c->d_todo, 2 * q + 16));
     HIPCHK(hipMemset(c->d_todo, 0, sizeof(uint32_t) * 16));            // count and ticket: the exact-walk kernel leaves them zero after every batch
     if (!c->d_sort1) {
         PCTCHK(dev_alloc(&c->d_sort1, 4 * kSortBuckets + 8));
@@ -2361,6 +2361,33 @@ int pct_route_owner_dev(const double *cuts, int world, int axis, int rank, const
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * (size_t)world, s));
     if (Q) route_owner_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(C, rank, d_q, (uint32_t)Q, d_counts, d_mine_ids, d_mine_q);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_owner_all_dev(const double *cuts, int world, int axis, const float *d_q, int64_t Q, uint32_t *d_counts, unsigned char *d_owner, void *stream)
+{
+    if (Q < 0 || (Q > 0 && (!d_q || !d_counts || !d_owner))) return fail(PCT_ERR_INVALID, "bad route_owner_all arguments");
+    RouteCuts C{};
+    PCTCHK(route_cuts(cuts, world, axis, &C));
+    PCTCHK(require_init());
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * (size_t)world, s));
+    if (Q) route_owner_all_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(C, d_q, (uint32_t)Q, d_counts, d_owner);
+    HIPCHK(hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_route_partition_dev(const uint32_t *offsets, int world, const unsigned char *d_owner, const float *d_q, int64_t Q, uint32_t *d_cursors,
+                            float *d_out_xyz, uint32_t *d_out_slot, void *stream)
+{
+    if (!offsets || world < 1 || world > kRouteMaxWorld || Q < 0 || (Q > 0 && (!d_owner || !d_q || !d_cursors || !d_out_xyz || !d_out_slot)))
+        return fail(PCT_ERR_INVALID, "bad route_partition arguments");
+    RouteOffsets O{};
+    for (int k = 0; k < world; k++) O.v[k] = offsets[k];
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(d_cursors, 0, sizeof(uint32_t) * (size_t)world, s));
+    if (Q) route_partition_kernel<<<ceil_div(Q, 256), 256, 0, s>>>(O, d_owner, d_q, (uint32_t)Q, d_cursors, d_out_xyz, d_out_slot);
     HIPCHK(hipGetLastError());
     return PCT_OK;
 }

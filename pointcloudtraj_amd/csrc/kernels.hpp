@@ -593,6 +593,36 @@ __global__ __launch_bounds__(256) void route_owner_kernel(RouteCuts C, int rank,
     }
 }
 
+// partitioned batches (every rank brings its OWN queries): owner of every query + counts per owner ...
+__global__ __launch_bounds__(256) void route_owner_all_kernel(RouteCuts C, const float *__restrict__ q, uint32_t Q, uint32_t *__restrict__ counts,
+                                                              unsigned char *__restrict__ owner)
+{
+    __shared__ uint32_t h[kRouteMaxWorld];
+    if (threadIdx.x < (uint32_t)kRouteMaxWorld) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Q) {
+        const int own = route_owner(C, (double)q[3 * i + C.axis]);
+        owner[i] = (unsigned char)own;
+        atomicAdd(&h[own], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)C.world && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+}
+// ... then the queries grouped by owner (segment k starts at off.v[k]; order inside a segment is arrival order of the atomics: every
+// record carries the slot it came from)
+struct RouteOffsets { uint32_t v[kRouteMaxWorld]; };
+__global__ __launch_bounds__(256) void route_partition_kernel(RouteOffsets off, const unsigned char *__restrict__ owner, const float *__restrict__ q, uint32_t Q,
+                                                              uint32_t *__restrict__ cursors, float *__restrict__ out_xyz, uint32_t *__restrict__ out_slot)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    const uint32_t o = owner[i];
+    const uint32_t p = off.v[o] + atomicAdd(&cursors[o], 1u);
+    out_xyz[3 * p] = q[3 * i]; out_xyz[3 * p + 1] = q[3 * i + 1]; out_xyz[3 * p + 2] = q[3 * i + 2];
+    out_slot[p] = i;
+}
+
 // the owner's answers as records: certified when the point found is STRICTLY nearer than the edge of the slab's halo (a point just
 // outside the halo at exactly that distance could tie with a lower index), otherwise flagged with d2 = -1
 __global__ __launch_bounds__(256) void route_certify_kernel(int axis, double lo_edge, double hi_edge, const float *__restrict__ mine_q,

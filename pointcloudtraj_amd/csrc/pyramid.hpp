@@ -365,7 +365,7 @@ __device__ __forceinline__ bool pyr_nn_search_fast(const GridDesc &G, int nlev, 
                                                    const float4 *__restrict__ pts, float qxf, float qyf, float qzf, uint32_t sub,
                                                    int cx, int cy, int cz, int L0,
                                                    int bxa, int bxb, int bya, int byb, int bza, int bzb,
-                                                   double &bd, uint32_t &bi, uint32_t &npts, uint32_t &nruns, uint32_t &nnodes)
+                                                   double &bd, uint32_t &bi, float &lim_out, uint32_t &npts, uint32_t &nruns, uint32_t &nnodes)
 {
     const float inf = __builtin_huge_valf();
     const float hf = (float)G.hd;
@@ -458,7 +458,10 @@ __device__ __forceinline__ bool pyr_nn_search_fast(const GridDesc &G, int nlev, 
     pyr_best_fold_step<kDppXor1>(B);
     pyr_best_fold_step<kDppXor2>(B);
     pyr_best_fold_step<kDppHalfMirror>(B);
-    if (!(B.m2 > B.m1 * (1.0f + 0x1p-19f) + 0x1p-90f)) return false;  // a second point inside the band (or nothing found at all)
+    // undecided: a second point inside the band (or nothing found at all).  Everything that can win or tie lies within lim_out of the
+    // query: the exact walk that takes over starts with that bound instead of discovering it
+    lim_out = (B.m1 * (1.0f + 0x1p-19f) + 0x1p-90f) * (1.0f + 0x1p-20f);
+    if (!(B.m2 > B.m1 * (1.0f + 0x1p-19f) + 0x1p-90f)) return false;
     if (B.bx == B.bx) {                                               // the winner is a point the walk saw: its exact distance, once
         bd = dist2((double)B.bx, (double)B.by, (double)B.bz, (double)qxf, (double)qyf, (double)qzf);
         bi = B.id;
@@ -527,8 +530,14 @@ __device__ __forceinline__ void pyr_answer(const GridDesc &G, const PyrDesc &PD,
     }
     if (undecided) {
         if (FAST) {
-            if (!pyr_nn_search_fast<COUNT>(G, PD.nlev, s_off, nodes, pts, qxf, qyf, qzf, sub, cx, cy, cz, L0, xa, xb, ya, yb, za, zb, bd, bi, npts, nruns, nnodes)) {
-                if (sub == 0) todo[2u + atomicAdd(&todo[0], 1u)] = slot;
+            float lim;
+            if (!pyr_nn_search_fast<COUNT>(G, PD.nlev, s_off, nodes, pts, qxf, qyf, qzf, sub, cx, cy, cz, L0, xa, xb, ya, yb, za, zb, bd, bi, lim, npts, nruns, nnodes)) {
+                // (measured: the exact walk right here instead of a list costs the kernel its registers: 1.15 against 1.18e9 q/s)
+                if (sub == 0) {
+                    const uint32_t e = atomicAdd(&todo[0], 1u);
+                    todo[2u + 2u * e] = slot;
+                    todo[3u + 2u * e] = __float_as_uint(lim);
+                }
                 return;
             }
         } else {
@@ -597,8 +606,29 @@ __global__ __launch_bounds__(256) void nn_grid_pyr_todo_kernel(GridDesc G, PyrDe
     __syncthreads();
     const uint32_t count = s_count, sub = threadIdx.x & (kCoop - 1);
     uint32_t npts = 0, nruns = 0, nnodes = 0;
-    for (uint32_t e = blockIdx.x * (256 / kCoop) + (threadIdx.x / kCoop); e < count; e += gridDim.x * (256 / kCoop))
-        pyr_answer<COUNT, false>(G, PD, s_off, nodes, hint, pts, cell_start, q, index_base, qsorted, todo[2u + e], sub, out_idx, out_d2, sorted_out, nullptr, npts, nruns, nnodes);
+    for (uint32_t e = blockIdx.x * (256 / kCoop) + (threadIdx.x / kCoop); e < count; e += gridDim.x * (256 / kCoop)) {
+        // the exact walk with the bound the fp32 walk established: everything that can win or tie is within `lim` of the query, so the
+        // walk prunes from its first node on (no stage 0, nothing excluded: ~10 dependent trips instead of ~30 for these stragglers)
+        const uint32_t slot = todo[2u + 2u * e];
+        const float lim = __uint_as_float(todo[3u + 2u * e]);
+        uint32_t t = slot;
+        float qxf, qyf, qzf;
+        if (qsorted) {
+            const float4 R = qsorted[slot];
+            qxf = R.x; qyf = R.y; qzf = R.z; t = sorted_out ? slot : __float_as_uint(R.w);
+        } else {
+            qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
+        }
+        const int cx = cell_coord(qxf, G.ox, G.inv_h, G.gx), cy = cell_coord(qyf, G.oy, G.inv_h, G.gy), cz = cell_coord(qzf, G.oz, G.inv_h, G.gz);
+        const int L0 = (int)hint[cell_lin(G, cx, cy, cz)];
+        double bd = (double)lim;                       // +inf when the fp32 walk found nothing (non-finite query)
+        uint32_t bi = kNoIndex;
+        pyr_nn_search<COUNT>(G, PD.nlev, s_off, nodes, pts, qxf, qyf, qzf, sub, cx, cy, cz, L0, 1, 0, 1, 0, 1, 0, bd, bi, npts, nruns, nnodes);
+        if (sub == 0) {
+            out_idx[t] = (bi == kNoIndex) ? kNoIndex : bi + index_base;
+            out_d2[t] = (bi == kNoIndex) ? __builtin_huge_val() : bd;
+        }
+    }
     pyr_commit_work<COUNT>(npts, nruns, nnodes, work);
     // the last block to finish leaves the list empty for the next batch (every block has read the count by then)
     __syncthreads();

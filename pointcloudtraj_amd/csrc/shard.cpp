@@ -239,6 +239,17 @@ struct pct_route {
     uint32_t h_counts[kRouteMaxWorld] = {};
     int64_t mine = 0, flagged = 0;
     uint64_t st_owned = 0, st_uncert = 0, st_batches = 0;
+    // partitioned batches (every rank brings its own queries): send side sized by this rank's Q, receive side by what the others route here
+    int64_t pq_cap = 0, pr_cap = 0, pf_cap = 0;
+    unsigned char *d_owner = nullptr;
+    uint32_t *d_pflag = nullptr, *d_pflag_ids = nullptr;
+    uint32_t *d_pcnt = nullptr, *d_pmat = nullptr, *d_sq_slot = nullptr, *d_rq_slot = nullptr, *d_plidx = nullptr, *d_pfidx = nullptr;
+    float *d_sq_xyz = nullptr, *d_rq_xyz = nullptr, *d_pfq_mine = nullptr, *d_pfq_all = nullptr;
+    double *d_pld2 = nullptr, *d_pfd2 = nullptr, *d_pfbest = nullptr;
+    int32_t *d_pfcand = nullptr;
+    RouteAnswer *d_ans_out = nullptr, *d_ans_in = nullptr;
+    uint32_t p_send[kRouteMaxWorld] = {};          // how many of my queries each rank owns
+    int64_t p_recv = 0;                            // how many queries the others (and I) route to me
 };
 
 namespace {
@@ -410,11 +421,123 @@ int phase_second_finish(pct_route *r, uint32_t *d_idx, double *d_d2, hipStream_t
     return PCT_OK;
 }
 
+// ---- partitioned batches: phases per rank (the exchanges between them are RCCL's or plain copies, see the entry points) ----
+int part_reserve_send(pct_route *r, int64_t Q)
+{
+    if (Q <= r->pq_cap) return PCT_OK;
+    HIPCHK(hipDeviceSynchronize());
+    r->pq_cap = 0;
+    const int64_t n = std::max<int64_t>(Q, 256);
+    if (grow(&r->d_owner, n) || grow(&r->d_pcnt, 4 * kRouteMaxWorld) || grow(&r->d_pmat, (int64_t)kRouteMaxWorld * kRouteMaxWorld + kRouteMaxWorld) || grow(&r->d_sq_slot, n) ||
+        grow(&r->d_sq_xyz, 3 * n) || grow(&r->d_ans_in, n) || grow(&r->d_pflag, 4) || grow(&r->d_pflag_ids, n) || grow(&r->d_pfq_mine, 3 * n))
+        return PCT_ERR_ALLOC;
+    r->pq_cap = n;
+    return PCT_OK;
+}
+int part_reserve_recv(pct_route *r, int64_t n_recv)
+{
+    if (n_recv <= r->pr_cap) return PCT_OK;
+    HIPCHK(hipDeviceSynchronize());
+    r->pr_cap = 0;
+    const int64_t n = std::max<int64_t>(n_recv + n_recv / 4, 256);
+    if (grow(&r->d_rq_slot, n) || grow(&r->d_rq_xyz, 3 * n) || grow(&r->d_plidx, n) || grow(&r->d_pld2, n) || grow(&r->d_ans_out, n)) return PCT_ERR_ALLOC;
+    r->pr_cap = n;
+    return PCT_OK;
+}
+int part_reserve_flag(pct_route *r, int64_t F)
+{
+    if (F <= r->pf_cap) return PCT_OK;
+    HIPCHK(hipDeviceSynchronize());
+    r->pf_cap = 0;
+    const int64_t n = std::max<int64_t>(2 * F, 256);
+    if (grow(&r->d_pfq_all, 3 * n) || grow(&r->d_pfidx, n) || grow(&r->d_pfd2, n) || grow(&r->d_pfbest, n) || grow(&r->d_pfcand, n)) return PCT_ERR_ALLOC;
+    r->pf_cap = n;
+    return PCT_OK;
+}
+
+int part_phase_count(pct_route *r, const float *d_q, int64_t Q, hipStream_t st)
+{
+    PCTCHK(part_reserve_send(r, Q));
+    PCTCHK(pct_route_owner_all_dev(r->cuts, r->world, r->axis, d_q, Q, r->d_pcnt, r->d_owner, st));
+    HIPCHK(hipMemcpyAsync(r->p_send, r->d_pcnt, sizeof(uint32_t) * (size_t)r->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return PCT_OK;
+}
+// mat[src * W + dst] = queries of rank src owned by rank dst (known to every rank)
+int part_phase_partition(pct_route *r, const float *d_q, int64_t Q, const uint32_t *mat, hipStream_t st)
+{
+    uint32_t off[kRouteMaxWorld];
+    uint32_t acc = 0;
+    for (int k = 0; k < r->world; k++) { off[k] = acc; acc += r->p_send[k]; }
+    PCTCHK(pct_route_partition_dev(off, r->world, r->d_owner, d_q, Q, r->d_pcnt + kRouteMaxWorld, r->d_sq_xyz, r->d_sq_slot, st));
+    int64_t n = 0;
+    for (int src = 0; src < r->world; src++) n += mat[(size_t)src * r->world + r->rank];
+    r->p_recv = n;
+    return part_reserve_recv(r, n);
+}
+int part_phase_answer(pct_route *r, hipStream_t st)
+{
+    const int64_t m = r->p_recv;
+    if (m == 0) return PCT_OK;
+    if (r->n_slab > 0) {
+        PCTCHK(pct_cloud_reserve_queries(r->slab, m));
+        PCTCHK(pct_nn_batch_dev(r->slab, PCT_ALGO_AUTO, r->d_rq_xyz, m, r->d_plidx, r->d_pld2, st));
+    } else {
+        HIPCHK(hipMemsetAsync(r->d_plidx, 0xFF, sizeof(uint32_t) * (size_t)m, st));
+        HIPCHK(hipMemsetAsync(r->d_pld2, 0, sizeof(double) * (size_t)m, st));
+    }
+    const double lo_edge = r->cuts[r->rank] - r->halo, hi_edge = r->cuts[r->rank + 1] + r->halo;
+    PCTCHK(pct_route_certify_dev(r->axis, lo_edge, hi_edge, r->d_rq_xyz, r->d_rq_slot, m, r->d_plidx, r->d_pld2, r->d_gid, r->d_ans_out, st));
+    r->st_owned += (uint64_t)m;
+    return PCT_OK;
+}
+int part_phase_scatter(pct_route *r, int64_t Q, uint32_t *d_idx, double *d_d2, hipStream_t st)
+{
+    PCTCHK(pct_route_scatter_dev(r->d_ans_in, Q, d_idx, d_d2, r->d_pflag, r->d_pflag_ids, st));
+    uint32_t f = 0;
+    HIPCHK(hipMemcpyAsync(&f, r->d_pflag, sizeof f, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    r->flagged = f;
+    r->st_batches++;
+    r->st_uncert += f;
+    if (f) {
+        std::vector<uint32_t> ids(f);
+        HIPCHK(hipMemcpy(ids.data(), r->d_pflag_ids, sizeof(uint32_t) * f, hipMemcpyDeviceToHost));
+        std::sort(ids.begin(), ids.end());
+        HIPCHK(hipMemcpy(r->d_pflag_ids, ids.data(), sizeof(uint32_t) * f, hipMemcpyHostToDevice));
+    }
+    return PCT_OK;
+}
+int part_phase_second_answer(pct_route *r, int64_t F, hipStream_t st)        // d_pfq_all holds every rank's uncertified queries, rank order
+{
+    if (r->n_slab > 0) {
+        PCTCHK(pct_cloud_reserve_queries(r->slab, F));
+        PCTCHK(pct_nn_batch_dev(r->slab, PCT_ALGO_AUTO, r->d_pfq_all, F, r->d_pfidx, r->d_pfd2, st));
+        PCTCHK(pct_route_to_global_dev(r->d_pfidx, F, r->d_gid, st));
+    } else {
+        HIPCHK(hipMemsetAsync(r->d_pfidx, 0xFF, sizeof(uint32_t) * (size_t)F, st));
+        std::vector<double> inf((size_t)F, std::numeric_limits<double>::infinity());
+        HIPCHK(hipMemcpyAsync(r->d_pfd2, inf.data(), sizeof(double) * (size_t)F, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    return PCT_OK;
+}
+int part_phase_second_finish(pct_route *r, int64_t F, int64_t my_off, uint32_t *d_idx, double *d_d2, hipStream_t st)      // d_pfbest / d_pfcand merged
+{
+    PCTCHK(pct_merge_finish_dev(r->d_pfcand, r->d_pfidx, F, st));
+    PCTCHK(pct_route_put_back_dev(r->d_pflag_ids, r->flagged, r->d_pfidx + my_off, r->d_pfbest + my_off, d_idx, d_d2, st));
+    return PCT_OK;
+}
+
 void route_free(pct_route *r)
 {
     if (!r) return;
     (void)hipDeviceSynchronize();
     if (r->slab) (void)pct_cloud_destroy(r->slab);
+    for (void *p : { (void *)r->d_pflag, (void *)r->d_pflag_ids, (void *)r->d_owner, (void *)r->d_pcnt, (void *)r->d_pmat, (void *)r->d_sq_slot, (void *)r->d_rq_slot, (void *)r->d_plidx, (void *)r->d_pfidx, (void *)r->d_sq_xyz,
+                     (void *)r->d_rq_xyz, (void *)r->d_pfq_mine, (void *)r->d_pfq_all, (void *)r->d_pld2, (void *)r->d_pfd2, (void *)r->d_pfbest, (void *)r->d_pfcand,
+                     (void *)r->d_ans_out, (void *)r->d_ans_in })
+        if (p) (void)hipFree(p);
     for (void *p : { (void *)r->d_gid, (void *)r->d_counts, (void *)r->d_mine_ids, (void *)r->d_lidx, (void *)r->d_flag, (void *)r->d_flag_ids, (void *)r->d_fidx, (void *)r->d_mine_q,
                      (void *)r->d_fq, (void *)r->d_ld2, (void *)r->d_fd2, (void *)r->d_fbest, (void *)r->d_fcand, (void *)r->d_send, (void *)r->d_recv })
         if (p) (void)hipFree(p);
@@ -678,6 +801,159 @@ int pct_shard_route_nn_world(pct_route *const *routes, int world, const float *d
             HIPCHK(hipMemcpy(routes[k]->d_fcand, cand.data(), sizeof(int32_t) * (size_t)f, hipMemcpyHostToDevice));
             PCTCHK(phase_second_finish(routes[k], d_idx[k], d_d2[k], st));
         }
+    }
+    return PCT_OK;
+}
+
+
+// ---- partitioned batches: every rank brings its OWN queries (weak scaling: the whole job answers W x Q queries per step) ----
+// The queries travel to the rank that owns their slab and the answers travel back: two variable-sized all-to-alls of 16 bytes per query
+// (grouped ncclSend / ncclRecv), nothing is replicated, nobody answers a query twice -- the form whose aggregate rate can grow with the
+// number of cards.  Three host synchronises per batch (share sizes, uncertified count, and the counts matrix in between).
+int pct_shard_route_nn_partitioned_dev(pct_route *r, const float *d_q, int64_t Q, uint32_t *d_idx, double *d_d2, void *stream)
+{
+    if (!r || !r->s || r->s->local || Q < 0 || (Q > 0 && (!d_q || !d_idx || !d_d2))) return sfail(PCT_ERR_INVALID, "bad route_nn_partitioned_dev arguments");
+    pct_shard *s = r->s;
+    const int W = r->world, me = r->rank;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PCTCHK(part_phase_count(r, d_q, Q, st));
+    // everybody learns everybody's shares
+    std::vector<uint32_t> mat((size_t)W * W);
+    HIPCHK(hipMemcpyAsync(r->d_pmat + (size_t)W * W, r->p_send, sizeof(uint32_t) * (size_t)W, hipMemcpyHostToDevice, st));
+    NCCLCHK(ncclAllGather(r->d_pmat + (size_t)W * W, r->d_pmat, (size_t)W, ncclUint32, s->comm, st));
+    HIPCHK(hipMemcpyAsync(mat.data(), r->d_pmat, sizeof(uint32_t) * (size_t)W * W, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    PCTCHK(part_phase_partition(r, d_q, Q, mat.data(), st));
+    auto all_to_all = [&](auto *send, const uint32_t *send_n, auto *recv, auto recv_n, size_t elem_bytes) -> int {      // segment k of `send` -> rank k
+        ncclResult_t nr = ncclGroupStart();
+        int64_t so = 0, ro = 0;
+        for (int k = 0; k < W && nr == ncclSuccess; k++) {
+            const int64_t ns = send_n[k], nv = recv_n(k);
+            if (k == me) {
+                if (ns && hipMemcpyAsync(reinterpret_cast<unsigned char *>(recv) + ro * elem_bytes, reinterpret_cast<const unsigned char *>(send) + so * elem_bytes, (size_t)ns * elem_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                    nr = ncclInternalError;
+            } else {
+                if (ns) nr = ncclSend(reinterpret_cast<const unsigned char *>(send) + so * elem_bytes, (size_t)ns * elem_bytes, ncclChar, k, s->comm, st);
+                if (nr == ncclSuccess && nv) nr = ncclRecv(reinterpret_cast<unsigned char *>(recv) + ro * elem_bytes, (size_t)nv * elem_bytes, ncclChar, k, s->comm, st);
+            }
+            so += ns; ro += nv;
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr != ncclSuccess || ne != ncclSuccess) return sfail(PCT_ERR_HIP, "all-to-all failed: %s", ncclGetErrorString(nr != ncclSuccess ? nr : ne));
+        return PCT_OK;
+    };
+    const auto from = [&](int k) { return (int64_t)mat[(size_t)k * W + me]; };          // what rank k routes to me
+    uint32_t back_n[kRouteMaxWorld];
+    for (int k = 0; k < W; k++) back_n[k] = mat[(size_t)k * W + me];
+    PCTCHK(all_to_all(r->d_sq_xyz, r->p_send, r->d_rq_xyz, from, 12));
+    PCTCHK(all_to_all(r->d_sq_slot, r->p_send, r->d_rq_slot, from, 4));
+    PCTCHK(part_phase_answer(r, st));
+    PCTCHK(all_to_all(r->d_ans_out, back_n, r->d_ans_in, [&](int k) { return (int64_t)r->p_send[k]; }, sizeof(RouteAnswer)));     // the answers go home
+    PCTCHK(part_phase_scatter(r, Q, d_idx, d_d2, st));
+    // second round: all uncertified queries of all ranks, answered by everybody
+    uint32_t fmine = (uint32_t)r->flagged;
+    std::vector<uint32_t> fall((size_t)W);
+    HIPCHK(hipMemcpyAsync(r->d_pmat + (size_t)W * W, &fmine, sizeof fmine, hipMemcpyHostToDevice, st));
+    NCCLCHK(ncclAllGather(r->d_pmat + (size_t)W * W, r->d_pmat, 1, ncclUint32, s->comm, st));
+    HIPCHK(hipMemcpyAsync(fall.data(), r->d_pmat, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t F = 0, my_off = 0;
+    for (int k = 0; k < W; k++) { if (k == me) my_off = F; F += fall[(size_t)k]; }
+    if (F == 0) return PCT_OK;
+    PCTCHK(part_reserve_flag(r, F));
+    PCTCHK(pct_route_gather_queries_dev(d_q, r->d_pflag_ids, r->flagged, r->d_pfq_mine, st));
+    {
+        ncclResult_t nr = ncclGroupStart();
+        int64_t ro = 0;
+        for (int k = 0; k < W && nr == ncclSuccess; k++) {
+            const int64_t nk = fall[(size_t)k];
+            if (k == me) {
+                if (nk && hipMemcpyAsync(r->d_pfq_all + 3 * ro, r->d_pfq_mine, sizeof(float) * 3 * (size_t)nk, hipMemcpyDeviceToDevice, st) != hipSuccess) nr = ncclInternalError;
+            } else {
+                if (r->flagged) nr = ncclSend(r->d_pfq_mine, sizeof(float) * 3 * (size_t)r->flagged, ncclChar, k, s->comm, st);
+                if (nr == ncclSuccess && nk) nr = ncclRecv(r->d_pfq_all + 3 * ro, sizeof(float) * 3 * (size_t)nk, ncclChar, k, s->comm, st);
+            }
+            ro += nk;
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr != ncclSuccess || ne != ncclSuccess) return sfail(PCT_ERR_HIP, "second-round gather failed: %s", ncclGetErrorString(nr != ncclSuccess ? nr : ne));
+    }
+    PCTCHK(part_phase_second_answer(r, F, st));
+    NCCLCHK(ncclAllReduce(r->d_pfd2, r->d_pfbest, (size_t)F, ncclDouble, ncclMin, s->comm, st));
+    PCTCHK(pct_merge_mask_dev(r->d_pfd2, r->d_pfbest, r->d_pfidx, r->d_pfcand, F, st));
+    NCCLCHK(ncclAllReduce(r->d_pfcand, r->d_pfcand, (size_t)F, ncclInt32, ncclMin, s->comm, st));
+    PCTCHK(part_phase_second_finish(r, F, my_off, d_idx, d_d2, st));
+    return PCT_OK;
+}
+
+// the same with every rank in this process: d_q[k] / Q[k] = rank k's own batch, d_idx[k] / d_d2[k] = its answers
+int pct_shard_route_nn_partitioned_world(pct_route *const *routes, int world, const float *const *d_q, const int64_t *Q, uint32_t *const *d_idx, double *const *d_d2, void *stream)
+{
+    if (!routes || !d_q || !Q || !d_idx || !d_d2 || world < 1 || world > kRouteMaxWorld) return sfail(PCT_ERR_INVALID, "bad route_nn_partitioned_world arguments");
+    const int W = world;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::vector<uint32_t> mat((size_t)W * W);
+    for (int k = 0; k < W; k++) {
+        if (!routes[k] || !routes[k]->s->local) return sfail(PCT_ERR_INVALID, "not a local world");
+        PCTCHK(part_phase_count(routes[k], d_q[k], Q[k], st));
+        for (int d = 0; d < W; d++) mat[(size_t)k * W + d] = routes[k]->p_send[d];
+    }
+    for (int k = 0; k < W; k++) PCTCHK(part_phase_partition(routes[k], d_q[k], Q[k], mat.data(), st));
+    for (int dst = 0; dst < W; dst++) {                  // queries to their owners
+        int64_t ro = 0;
+        for (int src = 0; src < W; src++) {
+            const int64_t n = mat[(size_t)src * W + dst];
+            int64_t so = 0;
+            for (int j = 0; j < dst; j++) so += mat[(size_t)src * W + j];
+            if (n) {
+                HIPCHK(hipMemcpyAsync(routes[dst]->d_rq_xyz + 3 * ro, routes[src]->d_sq_xyz + 3 * so, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
+                HIPCHK(hipMemcpyAsync(routes[dst]->d_rq_slot + ro, routes[src]->d_sq_slot + so, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToDevice, st));
+            }
+            ro += n;
+        }
+    }
+    for (int k = 0; k < W; k++) PCTCHK(part_phase_answer(routes[k], st));
+    for (int org = 0; org < W; org++) {                  // answers home: segment of rank `own`'s output that came from `org`
+        int64_t ro = 0;
+        for (int own = 0; own < W; own++) {
+            const int64_t n = mat[(size_t)org * W + own];
+            int64_t so = 0;
+            for (int j = 0; j < org; j++) so += mat[(size_t)j * W + own];
+            if (n) HIPCHK(hipMemcpyAsync(routes[org]->d_ans_in + ro, routes[own]->d_ans_out + so, sizeof(RouteAnswer) * (size_t)n, hipMemcpyDeviceToDevice, st));
+            ro += n;
+        }
+    }
+    int64_t F = 0;
+    std::vector<int64_t> foff((size_t)W);
+    for (int k = 0; k < W; k++) { PCTCHK(part_phase_scatter(routes[k], Q[k], d_idx[k], d_d2[k], st)); foff[(size_t)k] = F; F += routes[k]->flagged; }
+    if (F == 0) return PCT_OK;
+    for (int k = 0; k < W; k++) {
+        PCTCHK(part_reserve_flag(routes[k], F));
+        PCTCHK(pct_route_gather_queries_dev(d_q[k], routes[k]->d_pflag_ids, routes[k]->flagged, routes[k]->d_pfq_mine, st));
+    }
+    for (int dst = 0; dst < W; dst++)
+        for (int src = 0; src < W; src++)
+            if (routes[src]->flagged)
+                HIPCHK(hipMemcpyAsync(routes[dst]->d_pfq_all + 3 * foff[(size_t)src], routes[src]->d_pfq_mine, sizeof(float) * 3 * (size_t)routes[src]->flagged, hipMemcpyDeviceToDevice, st));
+    for (int k = 0; k < W; k++) PCTCHK(part_phase_second_answer(routes[k], F, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<double> best((size_t)F, std::numeric_limits<double>::infinity()), d((size_t)F);
+    std::vector<int32_t> cand((size_t)F, 0x7FFFFFFF);
+    std::vector<uint32_t> ix((size_t)F);
+    for (int k = 0; k < W; k++) {
+        HIPCHK(hipMemcpy(d.data(), routes[k]->d_pfd2, sizeof(double) * (size_t)F, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < F; i++) best[(size_t)i] = std::min(best[(size_t)i], d[(size_t)i]);
+    }
+    for (int k = 0; k < W; k++) {
+        HIPCHK(hipMemcpy(d.data(), routes[k]->d_pfd2, sizeof(double) * (size_t)F, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ix.data(), routes[k]->d_pfidx, sizeof(uint32_t) * (size_t)F, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < F; i++)
+            if (d[(size_t)i] == best[(size_t)i] && ix[(size_t)i] != 0xFFFFFFFFu) cand[(size_t)i] = std::min(cand[(size_t)i], (int32_t)ix[(size_t)i]);
+    }
+    for (int k = 0; k < W; k++) {
+        HIPCHK(hipMemcpy(routes[k]->d_pfbest, best.data(), sizeof(double) * (size_t)F, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(routes[k]->d_pfcand, cand.data(), sizeof(int32_t) * (size_t)F, hipMemcpyHostToDevice));
+        PCTCHK(part_phase_second_finish(routes[k], F, foff[(size_t)k], d_idx[k], d_d2[k], st));
     }
     return PCT_OK;
 }

@@ -28,6 +28,7 @@ def lib():
         L.pct_shard_destroy.argtypes = [vp]
         L.pct_shard_route_build.argtypes = [vp, vp, i64, i64, i64, C.c_double, C.POINTER(vp)]
         L.pct_shard_route_nn_dev.argtypes = [vp, vp, i64, vp, vp, vp]
+        L.pct_shard_route_nn_partitioned_dev.argtypes = [vp, vp, i64, vp, vp, vp]
         L.pct_shard_route_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pct_shard_route_destroy.argtypes = [vp]
         _lib = L
@@ -74,6 +75,10 @@ class Route:
 
     def nn_device(self, q_ptr: int, Q: int, idx_ptr: int, d2_ptr: int, stream: int = 0):
         _chk(lib().pct_shard_route_nn_dev(self.h, q_ptr, int(Q), idx_ptr, d2_ptr, stream), "pct_shard_route_nn_dev")
+
+    def nn_partitioned_device(self, q_ptr: int, Q: int, idx_ptr: int, d2_ptr: int, stream: int = 0):
+        """this rank's OWN Q queries -> its own Q answers (the queries travel to the owners of their slabs and the answers back)"""
+        _chk(lib().pct_shard_route_nn_partitioned_dev(self.h, q_ptr, int(Q), idx_ptr, d2_ptr, stream), "pct_shard_route_nn_partitioned_dev")
 
     def stats(self):
         sp, ow, un, ba = C.c_int64(), C.c_uint64(), C.c_uint64(), C.c_uint64()

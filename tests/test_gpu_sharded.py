@@ -176,6 +176,10 @@ torch.cuda.synchronize()
 c = E.Cloud(len(pts)); c.set_input(pts); c.build_grid()
 wi, wd = c.nn(q, E.ALGO_GRID)
 ok = np.array_equal(di.cpu().numpy().view(np.uint32), wi) and np.array_equal(dd.cpu().numpy(), wd)
+di.zero_(); dd.zero_()
+route.nn_partitioned_device(dq.data_ptr(), len(q), di.data_ptr(), dd.data_ptr(), torch.cuda.current_stream().cuda_stream)      # the weak-scaling form
+torch.cuda.synchronize()
+ok = ok and np.array_equal(di.cpu().numpy().view(np.uint32), wi) and np.array_equal(dd.cpu().numpy(), wd)
 print("stats", route.stats(), "equal", ok)
 route.close(); sh.close(); c.close(); dist.destroy_process_group()
 sys.exit(0 if ok else 1)
