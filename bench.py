@@ -70,16 +70,20 @@ def measured_counters(kernel: str, pattern: str = "*_bench_pmc.json", threads: i
     return best, src
 
 
-def bound_from_counters(cnt):
-    """what limits the kernel by its SQ counters: 'latency' when the waves spend most of their cycles waiting (SQ_WAIT_ANY over
-    SQ_WAVE_CYCLES above one half), 'valu' when the vector ALU issues in most busy cycles, else 'hbm' (the roofline the fraction is
-    taken against).  None without counters."""
+def bound_from_counters(cnt, kernel_ms=None):
+    """what limits the kernel by the committed counters: 'hbm' when the fabric traffic it causes (2 x FETCH_SIZE + WRITE_SIZE) moves at
+    half the HBM peak or more during the kernel's time -- the waves then wait on bandwidth; 'latency' when they wait (SQ_WAIT_ANY over half
+    of SQ_WAVE_CYCLES) while the traffic stays below that: dependent round trips; else 'valu'.  (None, None) without counters."""
     if not cnt or "SQ_WAVE_CYCLES" not in cnt:
         return None, None
     wait = cnt.get("SQ_WAIT_ANY", 0.0) / max(cnt["SQ_WAVE_CYCLES"], 1.0)
-    valu = cnt.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / max(cnt.get("SQ_BUSY_CYCLES", 0.0) * 4.0, 1.0)      # issue slots of 4 SIMDs per CU-cycle
-    detail = {"wait_fraction_of_wave_cycles": wait, "valu_issue_per_busy_cycle": valu, "l2_hit_rate": cnt.get("derived_l2_hit_rate")}
-    return ("latency" if wait > 0.5 else "hbm"), detail
+    traffic = cnt.get("derived_hbm_traffic_bytes_per_launch")
+    tfrac = (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kernel_ms else None
+    detail = {"wait_fraction_of_wave_cycles": wait, "traffic_fraction_of_hbm_peak": tfrac, "l2_hit_rate": cnt.get("derived_l2_hit_rate"),
+              "valu_instructions_per_wave": (cnt.get("SQ_INSTS_VALU", 0.0) / cnt["SQ_WAVES"]) if cnt.get("SQ_WAVES") else None}
+    if tfrac is not None and tfrac >= 0.5:
+        return "hbm", detail
+    return ("latency" if wait > 0.5 else "valu"), detail
 
 
 def clustered_probe(E, synth, torch, device, Q, steps=10):
@@ -130,11 +134,14 @@ def clustered_probe(E, synth, torch, device, Q, steps=10):
                 same = bool(np.array_equal(bi, oi[:2048].cpu().numpy().view(np.uint32)) and np.array_equal(bd, od[:2048].cpu().numpy()))
                 alg = 12 * w[0] + 8 * w[1] + 192 * w[2] + 24 * Q
                 pi = c.pyramid_info()
+                cntp, srcp = measured_counters("nn_grid_pyr_kernel", "*_pyr_pmc.json", threads=8 * Q) if (pi["levels"] and len(pts) > 1_000_000) else ({}, None)
+                boundp, detailp = bound_from_counters(cntp, km)      # scripts/probe_pyr.py pillar10m under rocprofv3 (profiles/r03_pyr_*)
                 legs[mode[0]] = {"index_build_ms": t_build, "ms_per_step": ms, "queries_per_s": Q / (ms * 1e-3), "kernel_ms": km,
                                  "kernel": "nn_grid_pyr_kernel (+ nn_grid_pyr_todo_kernel)" if pi["levels"] else "nn_grid_coop_kernel",
                                  "points_per_query": w[0] / Q, "cell_runs_per_query": w[1] / Q, "pyramid_node_visits_per_query": w[2] / Q,
                                  "algorithmic_bytes": int(alg), "algorithmic_bytes_rule": "12 B x points scanned + 8 B x cell runs + 192 B x node visits (8 boxes of 6 floats) + 24 B x Q",
                                  "achieved_GBs": alg / (km * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (km * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "bound": boundp, "bound_evidence": detailp, "traffic": cntp.get("derived_hbm_traffic_bytes_per_launch"), "traffic_source": srcp,
                                  "pyramid_levels": pi["levels"], "empty_cell_fraction": pi["empty_fraction"], "grid": c.grid_info(),
                                  "equals_streaming_kernel_on_2048_queries": same}
         out[name] = {"points": int(len(pts)), "queries_per_step": Q, **legs}
@@ -319,7 +326,7 @@ def c4_probe(E, synth, torch, device, Q):
         alg4 = 12 * ps4 + 8 * runs4 + 24 * Q
         cnt4, src4 = measured_counters("nn_grid_coop_kernel", "*_c4_pmc.json", threads=8 * Q)       # scripts/probe_c4.py under rocprofv3
         tr4 = cnt4.get("derived_hbm_traffic_bytes_per_launch")
-        bound4, detail4 = bound_from_counters(cnt4)
+        bound4, detail4 = bound_from_counters(cnt4, k4)
         del qd, oi, od
     out["c4_probe"] = {"what": "C4 on one card: 100,000,000 uniform points resident (1.2 GB SoA + 1.6 GB cell-sorted, beyond the 256 MiB Infinity Cache)",
                        "upload_ms": 1e3 * (t2 - t1), "index_build_ms": 1e3 * (t3 - t2), "indexed_4096_queries_ms_host_buffers": float(np.median(ts)),
@@ -795,7 +802,7 @@ def main():
     traffic = cnt.get("derived_hbm_traffic_bytes_per_launch")
     if c4:
         cnt, cnt_src, traffic = {}, None, None       # the committed PMC passes are of the N = 1 command
-    bound, bound_detail = bound_from_counters(cnt)
+    bound, bound_detail = bound_from_counters(cnt, k_ms)
     value = Q / elapsed * a.steps                    # merged answers per second (never multiplied by the rank count)
     scaling_kind = "strong" if c4 else "weak"
     index_range = None

@@ -348,10 +348,14 @@ int ensure_stage(pct_cloud *c, size_t bytes)
 // to those of 0..n-1 and no record may sit outside its slab / cell; anything else is a wrong index and is reported, not served.
 int finish_build(pct_cloud *c, const GridDesc &G, hipError_t e, hipStream_t s)
 {
-    if (e == hipSuccess) e = hipMemcpyAsync(c->h_gbcheck, c->d_gbcheck, sizeof(GbCheck), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_gbcheck, c->d_gbcheck, sizeof(GbCheck) * kGbCheckSlots, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(PCT_ERR_HIP, "grid build failed: %s", hipGetErrorString(e));
-    const GbCheck k = *c->h_gbcheck;
+    GbCheck k{};
+    for (int i = 0; i < kGbCheckSlots; i++) {
+        k.sum_ids += c->h_gbcheck[i].sum_ids; k.xor_ids ^= c->h_gbcheck[i].xor_ids;
+        k.misplaced += c->h_gbcheck[i].misplaced; k.empty_cells += c->h_gbcheck[i].empty_cells;
+    }
     c->last_check = k;
     const uint64_t n = (uint64_t)c->count;
     const uint64_t want_sum = n * (n - 1) / 2;
@@ -1283,8 +1287,8 @@ static int cloud_create_impl(int64_t capacity, bool host_mapped, pct_cloud **out
         s = dev_alloc(&c->x, (size_t)c->cap4 + 4) || dev_alloc(&c->y, (size_t)c->cap4 + 4) || dev_alloc(&c->z, (size_t)c->cap4 + 4);
     if (!s) s = dev_alloc(&c->d_work, kWorkSlots);
     if (!s) s = dev_alloc(&c->d_bbox, (size_t)1024 * 6);
-    if (!s) s = dev_alloc(&c->d_gbcheck, 1);
-    if (!s && hipHostMalloc((void **)&c->h_gbcheck, sizeof(GbCheck), hipHostMallocDefault) != hipSuccess) s = fail(PCT_ERR_ALLOC, "hipHostMalloc failed");
+    if (!s) s = dev_alloc(&c->d_gbcheck, kGbCheckSlots);
+    if (!s && hipHostMalloc((void **)&c->h_gbcheck, sizeof(GbCheck) * kGbCheckSlots, hipHostMallocDefault) != hipSuccess) s = fail(PCT_ERR_ALLOC, "hipHostMalloc failed");
     if (!s) s = mapped_alloc(&c->h_xout, &c->d_xout, kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xin, &c->d_xin, 3 * kExpressMaxQ);
     if (!s) s = mapped_alloc(&c->h_xr, &c->d_xr, kExpressMaxQ);

@@ -33,6 +33,7 @@ struct GbDesc {
 // duplicated / lost / stale record breaks), no record may sit outside its slab, and the number of empty cells comes for free.
 // A mismatch makes pct_cloud_build_grid FAIL (PCT_ERR_INTERNAL) instead of handing out an index that answers wrongly.
 struct GbCheck { unsigned long long sum_ids; uint32_t xor_ids, misplaced, empty_cells, pad; };
+constexpr int kGbCheckSlots = 64;      // blocks add into slot blockIdx & 63 (thousands of blocks on one word serialise: +36 us at 10 M points); the host sums
 
 // zeroes the build's counters (a kernel of this library on the build's stream, not a runtime memset: one thing less between the
 // launches that is not ours)
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void gb_zero_kernel(uint32_t *__restrict__ a, 
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = 0u;
-    if (i == 0 && chk) { chk->sum_ids = 0ull; chk->xor_ids = 0u; chk->misplaced = 0u; chk->empty_cells = 0u; chk->pad = 0u; }
+    if (i < (uint32_t)kGbCheckSlots && chk) { chk[i].sum_ids = 0ull; chk[i].xor_ids = 0u; chk[i].misplaced = 0u; chk[i].empty_cells = 0u; chk[i].pad = 0u; }
 }
 
 // fold a thread's share of the check over the block (LDS), one set of global atomics per block
@@ -64,9 +65,10 @@ __device__ __forceinline__ void gb_check_commit(unsigned long long sum, uint32_t
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&chk->sum_ids, s_sum); atomicXor(&chk->xor_ids, s_xor);
-        if (s_bad) atomicAdd(&chk->misplaced, s_bad);
-        if (s_empty) atomicAdd(&chk->empty_cells, s_empty);
+        GbCheck *slot = chk + (blockIdx.x & (kGbCheckSlots - 1));
+        atomicAdd(&slot->sum_ids, s_sum); atomicXor(&slot->xor_ids, s_xor);
+        if (s_bad) atomicAdd(&slot->misplaced, s_bad);
+        if (s_empty) atomicAdd(&slot->empty_cells, s_empty);
     }
 }
 
