@@ -21,8 +21,15 @@
  *   - kd_nearest* on exact distance ties: the node the reference's own walk returns -- the root if it is
  *     among the tied nodes (it is the initial guess and only a strictly smaller distance displaces it,
  *     :432-436), otherwise the tied node reached first by "nearer subtree, node, farther subtree" (:345-402)
+ *   - any dimension, any double: a 3-D tree whose coordinates are all fp32 values (what the *f entry points insert, the
+ *     planner's only use) is mirrored into an fp32 cloud; a tree of another dimension, or one that was handed a double
+ *     fp32 cannot hold, keeps fp64 columns in HBM and is answered by exhaustive fp64 kernels with the same sums in the
+ *     same order (:267-272, :379-382) -- same tie rule, same range order
  * Documented differences:
- *   - only k == 3 is served by the device path; kd_create(k != 3) returns NULL
+ *   - kd_create(k) serves 1 <= k <= 1024 (NULL otherwise)
+ *   - the x,y,z forms (kd_insert3*, kd_nearest3*, kd_nearest_range3*) refuse trees of more than 3 dimensions, where the
+ *     reference reads past its 3-element buffer (:243-259, :493-535); kd_res_item3* leave their arguments alone on trees of
+ *     fewer than 3 dimensions
  *   - every query needs a HIP device; there is no host fallback (queries return NULL and
  *     print a diagnostic when the device is missing)
  */

@@ -166,6 +166,24 @@ int pct_cloud_crop_to(pct_cloud *src, const double q[3], double r, pct_cloud *ds
 int pct_radius_indices_batch_q64(pct_cloud *c, const double *q, const double *r, int64_t K, uint32_t *ids_out, int64_t cap_per_query,
                                  int64_t *counts_out);
 
+/* ---- node sets of any dimension with fp64 coordinates (the general form of the kd_* API: kd_create(k), double positions --
+ * Utils/kdtree/src/kdtree.c:112-131, 167-209).  Rows of `dim` doubles in HBM, insertion order = node number; every distance is
+ * the reference's sum  s = 0; for i < dim: s += (row[i] - q[i])^2  in that order, in fp64, without contraction
+ * (kdtree.c:267-272, 379-382, 420-423).  Exhaustive kernels: these sets are search trees of a planner (10^3 .. 10^6 nodes), not
+ * obstacle clouds -- 3-D fp32 clouds belong in a pct_cloud. */
+typedef struct pct_nodeset pct_nodeset;
+int pct_nodeset_create(int dim, int64_t capacity, pct_nodeset **out);      /* 1 <= dim <= 1024; capacity grows on append */
+int pct_nodeset_destroy(pct_nodeset *s);
+int pct_nodeset_clear(pct_nodeset *s);
+int64_t pct_nodeset_size(const pct_nodeset *s);
+int pct_nodeset_dim(const pct_nodeset *s);
+int pct_nodeset_append(pct_nodeset *s, const double *rows, int64_t n);     /* n rows of dim doubles, host memory */
+/* nearest node of ONE query (dim doubles): idx = the LOWEST node number at the minimum distance, d2 = that distance, ties = how
+ * many nodes attain it.  Empty set: idx = PCT_NO_INDEX, d2 = +inf, ties = 0. */
+int pct_nodeset_nearest(pct_nodeset *s, const double *q, uint32_t *idx, double *d2, uint32_t *ties);
+/* node numbers with d2 <= r2, ascending; *n_out = number of hits (may exceed cap; only cap written) */
+int pct_nodeset_radius_indices_r2(pct_nodeset *s, const double *q, double r2, uint32_t *idx_out, int64_t cap, int64_t *n_out);
+
 typedef struct pct_inflate_params {
     double start[3];        /* start_pt */
     double sample_range;    /* early-out: |p - start| > sample_range + max_radius */

@@ -164,7 +164,7 @@ int okd_insert(okd_tree *t, const double *pos, void *data)
     return 0;
 }
 
-#define OKD_MAXDIM 16
+#define OKD_MAXDIM 1024        /* the *f forms widen onto the stack; kd_create(k) beyond it is refused */
 
 /* kdtree.c:211-242: float coordinates are widened to double, nothing else. */
 int okd_insertf(okd_tree *t, const float *pos, void *data)
@@ -260,6 +260,7 @@ int okd_nearest_id(okd_tree *t, const double *q, int32_t *id_out, double *d2_out
 {
     if (!t || !t->has_box) return -1;            /* kdtree.c:412-413 */
     double bmin[OKD_MAXDIM], bmax[OKD_MAXDIM];
+    if (t->dim > OKD_MAXDIM) return -1;
     memcpy(bmin, t->box_min, sizeof(double) * t->dim);
     memcpy(bmax, t->box_max, sizeof(double) * t->dim);
     struct okd_nn_ctx c = { t, q, bmin, bmax, 0, 0 };
@@ -285,6 +286,7 @@ okd_res *okd_nearest(okd_tree *t, const double *q)
 okd_res *okd_nearestf(okd_tree *t, const float *q)
 {
     double w[OKD_MAXDIM];
+    if (t->dim > OKD_MAXDIM) return 0;
     for (int i = 0; i < t->dim; i++) w[i] = q[i];
     return okd_nearest(t, w);
 }
@@ -340,6 +342,7 @@ okd_res *okd_nearest_range(okd_tree *t, const double *q, double range)
 okd_res *okd_nearest_rangef(okd_tree *t, const float *q, float range)
 {
     double w[OKD_MAXDIM];
+    if (t->dim > OKD_MAXDIM) return 0;
     for (int i = 0; i < t->dim; i++) w[i] = q[i];
     return okd_nearest_range(t, w, range);
 }

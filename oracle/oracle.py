@@ -186,6 +186,70 @@ class PortKD:
         return cnt
 
 
+class _AnyDimKD:
+    """kd_create(k) / kd_insert / kd_nearest / kd_nearest_range with double positions through the plain C API of either library
+    (`pre` = "kd_" on the reference, "okd_" on the port); payload of row i is (void*)(i+1)."""
+
+    def __init__(self, lib, pre, dim):
+        self.L, self.pre, self.dim, self.n = lib, pre, int(dim), 0
+        dp, vp = C.POINTER(C.c_double), C.c_void_p
+        f = lambda n: getattr(lib, pre + n)                      # noqa: E731
+        f("create").restype = vp; f("create").argtypes = [C.c_int]
+        f("free").argtypes = [vp]
+        f("insert").argtypes = [vp, dp, vp]
+        f("nearest").restype = vp; f("nearest").argtypes = [vp, dp]
+        f("nearest_range").restype = vp; f("nearest_range").argtypes = [vp, dp, C.c_double]
+        for n in ("res_free", "res_size", "res_end", "res_next"):
+            f(n).argtypes = [vp]
+        f("res_item_data").restype = vp; f("res_item_data").argtypes = [vp]
+        self.f = f
+        self.h = f("create")(self.dim)
+
+    def close(self):
+        if self.h:
+            self.f("free")(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insert(self, rows):
+        rows = np.ascontiguousarray(rows, np.float64).reshape(-1, self.dim)
+        for p in rows:
+            if self.f("insert")(self.h, p.ctypes.data_as(C.POINTER(C.c_double)), C.c_void_p(self.n + 1)):
+                raise MemoryError
+            self.n += 1
+
+    def nearest(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, self.dim)
+        ids = np.empty(len(q), np.int32)
+        for i, qq in enumerate(q):
+            r = self.f("nearest")(self.h, qq.ctypes.data_as(C.POINTER(C.c_double)))
+            ids[i] = int(self.f("res_item_data")(r) or 0) - 1
+            self.f("res_free")(r)
+        return ids
+
+    def range_ids(self, q, r):
+        q = np.ascontiguousarray(q, np.float64).reshape(self.dim)
+        rs = self.f("nearest_range")(self.h, q.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(r))
+        out = []
+        while not self.f("res_end")(rs):
+            out.append(int(self.f("res_item_data")(rs) or 0) - 1)
+            self.f("res_next")(rs)
+        assert len(out) == self.f("res_size")(rs)
+        self.f("res_free")(rs)
+        return np.asarray(out, np.int32)
+
+
+def RefKDN(dim):
+    """the reference's compiled kdtree.c, any dimension, double positions"""
+    return _AnyDimKD(ref_libs()[0], "kd_", dim)
+
+
+def PortKDN(dim):
+    """the CPU restatement (oracle/kdtree_port.c), any dimension, double positions"""
+    return _AnyDimKD(port_lib(), "okd_", dim)
+
+
 class RefKD:
     """The reference's compiled kdtree.c."""
 

@@ -39,7 +39,7 @@ def build_all(force: bool = False, verbose: bool = False) -> None:
     hdrs = [os.path.join(ROOT, "include", "pct_engine.h"), os.path.join(ROOT, "include", "kdtree", "kdtree.h"),
             os.path.join(ROOT, "include", "kdtree", "kdtree_ext.h")]
     hdrs += [os.path.join(ROOT, "include", "pct_voxel.h"), os.path.join(ROOT, "include", "pct_traj.h")]
-    eng_units = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "voxel.hip"), os.path.join(CSRC, "traj.hip")]
+    eng_units = [os.path.join(CSRC, "engine.hip"), os.path.join(CSRC, "voxel.hip"), os.path.join(CSRC, "traj.hip"), os.path.join(CSRC, "nodeset.hip")]
     eng_src = eng_units + [os.path.join(CSRC, f) for f in ("kernels.hpp", "gridbuild.hpp", "pyramid.hpp", "bernstein.hpp", "brute2.hpp", "ring.hpp", "ring_host.inc", "engine_internal.hpp")]
     if force or _stale(ENGINE_SO, eng_src + hdrs):
         cmd = [HIPCC, *COMMON, "-o", ENGINE_SO, *eng_units]

@@ -17,8 +17,11 @@
 //
 // Exact distance ties in kd_nearest* resolve to the node the reference's own walk returns (reference_tie_winner below;
 // the batched kdx_* extensions and the obstacle-cloud engine keep "lowest index").
-// Deliberate differences (documented in include/kdtree/kdtree.h): k == 3 only; stored coordinates must be representable in fp32 (always
-// true for the *f entry points, which are the only ones the planner uses); no host fallback.
+// Any k and any double: a 3-D tree whose coordinates are all representable in fp32 (always true for the *f entry points, the only
+// ones the planner uses) is the fast case above; a tree of another dimension, or one that was handed a double fp32 cannot hold,
+// keeps its rows as fp64 columns in a pct_nodeset (csrc/nodeset.hip: exhaustive fp64 kernels, the same sums in the same order) and
+// is answered from there -- same tie rule, same range order.  The batched kdx_* extensions serve the fast case only.
+// Deliberate differences (documented in include/kdtree/kdtree.h): 1 <= k <= 1024; no host fallback.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -34,6 +37,12 @@
 
 namespace {
 constexpr int32_t NIL = -1;
+constexpr int kMaxDim = 1024;
+
+void three_only(const char *what)
+{
+    std::fprintf(stderr, "[libkdtree/pct] %s: the x,y,z forms serve trees of at most 3 dimensions\n", what);
+}
 
 void complain(const char *what)
 {
@@ -43,11 +52,14 @@ void complain(const char *what)
 
 struct kdtree {
     int dim = 3;
-    std::vector<double> pos;      // 3 per node, insertion order (fp64 as the reference stores them)
-    std::vector<float> posf;      // the same, narrowed (exact) -- what is mirrored to HBM
+    bool generic = false;         // dim != 3, or some coordinate is not an fp32 value: the device copy is a pct_nodeset of fp64 columns
+    std::vector<double> pos;      // dim per node, insertion order (fp64 as the reference stores them)
+    std::vector<float> posf;      // 3-D fp32 trees: the same, narrowed (exact) -- what is mirrored to HBM
+    pct_nodeset *nodes = nullptr; // generic trees
+    int64_t nsynced = 0;          // rows [0, nsynced) are in the node set
     std::vector<void *> data;
     std::vector<int32_t> lo, hi, parent;
-    std::vector<uint8_t> axis;
+    std::vector<uint16_t> axis;
     void (*destr)(void *) = nullptr;
     pct_cloud *cloud = nullptr;
     int64_t synced = 0;           // nodes [0, synced) are in HBM
@@ -97,6 +109,32 @@ int sync_device(kdtree *t)
     return 0;
 }
 
+// generic trees: bring the fp64 columns up to date
+int sync_nodes(kdtree *t)
+{
+    const int64_t n = t->count();
+    if (!t->nodes) {
+        if (pct_nodeset_create(t->dim, std::max<int64_t>(n, 1024), &t->nodes) != PCT_OK) { complain("pct_nodeset_create"); t->nodes = nullptr; return -1; }
+        t->nsynced = 0;
+    }
+    if (t->nsynced < n) {
+        if (pct_nodeset_append(t->nodes, t->pos.data() + (size_t)t->dim * t->nsynced, n - t->nsynced) != PCT_OK) { complain("node set upload"); return -1; }
+        t->nsynced = n;
+    }
+    return 0;
+}
+
+// a 3-D fp32 tree met a double that fp32 cannot hold: from here on its device copy is the fp64 node set
+void make_generic(kdtree *t)
+{
+    t->generic = true;
+    if (t->cloud) { pct_cloud_destroy(t->cloud); t->cloud = nullptr; }
+    t->synced = 0;
+    t->aux_mapped = nullptr;
+    t->posf.clear(); t->posf.shrink_to_fit();
+    t->aux.clear(); t->aux.shrink_to_fit();
+}
+
 // kdtree.c:136-148: destructor order = left subtree, right subtree, node
 void run_destructors(kdtree *t)
 {
@@ -119,7 +157,7 @@ bool walk_path(const kdtree *t, int32_t n, const double *q, double range, std::v
     path.clear();
     for (int32_t c = n, a = t->parent[n]; a != NIL; c = a, a = t->parent[a]) {
         const int ax = t->axis[a];
-        const double dx = q[ax] - t->pos[3 * (size_t)a + ax];
+        const double dx = q[ax] - t->pos[(size_t)t->dim * a + ax];
         const int32_t near_child = dx <= 0.0 ? t->lo[a] : t->hi[a];
         if (c == near_child) path.push_back(0);
         else {
@@ -170,7 +208,7 @@ int32_t reference_tie_winner(const kdtree *t, const double *q, const uint32_t *t
         cur.clear();
         for (int32_t c = id, a = t->parent[id]; a != NIL; c = a, a = t->parent[a]) {
             const int ax = t->axis[a];
-            const double dx = q[ax] - t->pos[3 * (size_t)a + ax];
+            const double dx = q[ax] - t->pos[(size_t)t->dim * a + ax];
             const int32_t near_child = dx <= 0.0 ? t->lo[a] : t->hi[a];
             cur.push_back(c == near_child ? 0 : 2);
         }
@@ -199,10 +237,16 @@ int64_t host_max_nodes()
 
 inline double node_d2(const kdtree *t, int64_t i, const double *q)      // kdtree.c:379-382
 {
-    const double dx = t->pos[3 * (size_t)i] - q[0], dy = t->pos[3 * (size_t)i + 1] - q[1], dz = t->pos[3 * (size_t)i + 2] - q[2];
-    double s = dx * dx;
-    s = s + dy * dy;
-    s = s + dz * dz;
+    if (t->dim == 3) {
+        const double dx = t->pos[3 * (size_t)i] - q[0], dy = t->pos[3 * (size_t)i + 1] - q[1], dz = t->pos[3 * (size_t)i + 2] - q[2];
+        double s = dx * dx;
+        s = s + dy * dy;
+        s = s + dz * dz;
+        return s;
+    }
+    const double *p = &t->pos[(size_t)t->dim * i];
+    double s = 0.0;
+    for (int k = 0; k < t->dim; k++) { const double d = p[k] - q[k]; s = s + d * d; }
     return s;
 }
 
@@ -228,8 +272,8 @@ extern "C" {
 
 struct kdtree *kd_create(int k)
 {
-    if (k != 3) {
-        std::fprintf(stderr, "[libkdtree/pct] kd_create(%d): only k == 3 is served by the device path\n", k);
+    if (k < 1 || k > 1024) {
+        std::fprintf(stderr, "[libkdtree/pct] kd_create(%d): 1 <= k <= 1024\n", k);
         return nullptr;
     }
     if (pct_device_count() <= 0) {
@@ -237,6 +281,7 @@ struct kdtree *kd_create(int k)
         return nullptr;
     }
     kdtree *t = new (std::nothrow) kdtree();
+    if (t) { t->dim = k; t->generic = (k != 3); }
     return t;
 }
 
@@ -247,6 +292,9 @@ void kd_clear(struct kdtree *t)
     t->lo.clear(); t->hi.clear(); t->parent.clear(); t->axis.clear();
     t->synced = 0;
     if (t->cloud) pct_cloud_upload_aos(t->cloud, nullptr, 0, 12);
+    t->nsynced = 0;
+    if (t->nodes) pct_nodeset_clear(t->nodes);
+    t->generic = (t->dim != 3);                       // an emptied 3-D tree is an fp32 tree again until told otherwise
 }
 
 void kd_free(struct kdtree *t)
@@ -254,21 +302,22 @@ void kd_free(struct kdtree *t)
     if (!t) return;
     kd_clear(t);
     if (t->cloud) pct_cloud_destroy(t->cloud);
+    if (t->nodes) pct_nodeset_destroy(t->nodes);
     delete t;
 }
 
 void kd_data_destructor(struct kdtree *t, void (*destr)(void *)) { t->destr = destr; }
 
 // kdtree.c:167-209: strictly smaller on the split axis -> negative side, ties and larger ->
-// positive side; a new leaf splits on (parent axis + 1) % 3, the root on axis 0.
+// positive side; a new leaf splits on (parent axis + 1) % dim, the root on axis 0.
 int kd_insert(struct kdtree *t, const double *p, void *data)
 {
-    float pf[3];
-    for (int i = 0; i < 3; i++) {
-        pf[i] = (float)p[i];
-        if ((double)pf[i] != p[i]) {
-            std::fprintf(stderr, "[libkdtree/pct] kd_insert: coordinate %.17g is not representable in fp32 (device cloud is fp32)\n", p[i]);
-            return -1;
+    const int dim = t->dim;
+    float pf[3] = { 0.0f, 0.0f, 0.0f };
+    if (!t->generic) {
+        for (int i = 0; i < 3; i++) {
+            pf[i] = (float)p[i];
+            if (!((double)pf[i] == p[i])) { make_generic(t); break; }     // a double fp32 cannot hold (or a NaN): fp64 columns from here on
         }
     }
     const int32_t id = (int32_t)t->count();
@@ -279,35 +328,42 @@ int kd_insert(struct kdtree *t, const double *p, void *data)
             int32_t cur = 0;
             for (;;) {
                 const int a = t->axis[cur];
-                int32_t &link = (p[a] < t->pos[3 * (size_t)cur + a]) ? t->lo[cur] : t->hi[cur];
-                if (link == NIL) { link = id; ax = (a + 1) % 3; par = cur; break; }
+                int32_t &link = (p[a] < t->pos[(size_t)dim * cur + a]) ? t->lo[cur] : t->hi[cur];
+                if (link == NIL) { link = id; ax = (a + 1) % dim; par = cur; break; }
                 cur = link;
             }
         }
-        t->pos.insert(t->pos.end(), p, p + 3);
-        t->posf.insert(t->posf.end(), pf, pf + 3);
+        t->pos.insert(t->pos.end(), p, p + dim);
+        if (!t->generic) {
+            t->posf.insert(t->posf.end(), pf, pf + 3);
+            const double a[4] = { p[0], p[1], p[2], 0.0 };               // until kdx_set_node_aux says otherwise
+            t->aux.insert(t->aux.end(), a, a + 4);
+        }
         t->data.push_back(data);
-        { const double a[4] = { p[0], p[1], p[2], 0.0 }; t->aux.insert(t->aux.end(), a, a + 4); }   // until kdx_set_node_aux says otherwise
         t->lo.push_back(NIL); t->hi.push_back(NIL); t->parent.push_back(par);
-        t->axis.push_back((uint8_t)ax);
+        t->axis.push_back((uint16_t)ax);
     } catch (const std::bad_alloc &) {
         return -1;
     }
     return 0;
 }
 
-int kd_insertf(struct kdtree *t, const float *p, void *data)
+int kd_insertf(struct kdtree *t, const float *p, void *data)          // kdtree.c:211-241: dim floats widened
 {
-    const double w[3] = { p[0], p[1], p[2] };
+    double w[kMaxDim];
+    for (int i = 0; i < t->dim; i++) w[i] = p[i];
     return kd_insert(t, w, data);
 }
+// kdtree.c:243-259 hand a 3-element buffer to kd_insert whatever the tree's dimension (it reads past the buffer for k > 3): refused here
 int kd_insert3(struct kdtree *t, double x, double y, double z, void *data)
 {
+    if (t->dim > 3) return three_only("kd_insert3"), -1;
     const double w[3] = { x, y, z };
     return kd_insert(t, w, data);
 }
 int kd_insert3f(struct kdtree *t, float x, float y, float z, void *data)
 {
+    if (t->dim > 3) return three_only("kd_insert3f"), -1;
     const double w[3] = { x, y, z };
     return kd_insert(t, w, data);
 }
@@ -324,9 +380,25 @@ struct kdres *kd_nearest(struct kdtree *t, const double *q)
         r->size = 1;
         return r;
     }
-    if (sync_device(t)) return nullptr;
     uint32_t idx = PCT_NO_INDEX, ties = 0;
     double d2 = 0;
+    if (t->generic) {                                     // fp64 columns of any dimension (csrc/nodeset.hip)
+        if (sync_nodes(t)) return nullptr;
+        if (pct_nodeset_nearest(t->nodes, q, &idx, &d2, &ties) != PCT_OK) { complain("kd_nearest"); return nullptr; }
+        if (ties > 1) {
+            std::vector<uint32_t> tied((size_t)ties);
+            int64_t nt = 0;
+            if (pct_nodeset_radius_indices_r2(t->nodes, q, d2, tied.data(), (int64_t)tied.size(), &nt) != PCT_OK) { complain("kd_nearest (tie set)"); return nullptr; }
+            if (nt > 1) idx = (uint32_t)reference_tie_winner(t, q, tied.data(), std::min<int64_t>(nt, (int64_t)tied.size()));
+        }
+        kdres *r = new (std::nothrow) kdres();
+        if (!r) return nullptr;
+        r->tree = t;
+        r->items.push_back((int32_t)idx);
+        r->size = 1;
+        return r;
+    }
+    if (sync_device(t)) return nullptr;
     if (pct_nn_batch_q64_ties(t->cloud, q, 1, &idx, &d2, &ties) != PCT_OK) { complain("kd_nearest"); return nullptr; }
     if (ties != 1) {
         // several nodes at exactly the minimum distance (ties > 1), or a path that does not count them (0: trees beyond 16384
@@ -345,16 +417,20 @@ struct kdres *kd_nearest(struct kdtree *t, const double *q)
 }
 struct kdres *kd_nearestf(struct kdtree *t, const float *q)
 {
-    const double w[3] = { q[0], q[1], q[2] };
+    if (!t) return nullptr;
+    double w[kMaxDim];
+    for (int i = 0; i < t->dim; i++) w[i] = q[i];
     return kd_nearest(t, w);
 }
 struct kdres *kd_nearest3(struct kdtree *t, double x, double y, double z)
 {
+    if (t && t->dim > 3) return three_only("kd_nearest3"), nullptr;
     const double w[3] = { x, y, z };
     return kd_nearest(t, w);
 }
 struct kdres *kd_nearest3f(struct kdtree *t, float x, float y, float z)
 {
+    if (t && t->dim > 3) return three_only("kd_nearest3f"), nullptr;
     const double w[3] = { x, y, z };
     return kd_nearest(t, w);
 }
@@ -375,26 +451,34 @@ struct kdres *kd_nearest_range(struct kdtree *t, const double *q, double range)
         delete r;
         return out;
     }
-    if (sync_device(t)) { delete r; return nullptr; }
     std::vector<uint32_t> hits((size_t)n);
     int64_t nh = 0;
-    if (pct_radius_indices_q64(t->cloud, q, range, hits.data(), n, &nh) != PCT_OK) { complain("kd_nearest_range"); delete r; return nullptr; }
+    if (t->generic) {
+        if (sync_nodes(t)) { delete r; return nullptr; }
+        if (pct_nodeset_radius_indices_r2(t->nodes, q, range * range, hits.data(), n, &nh) != PCT_OK) { complain("kd_nearest_range"); delete r; return nullptr; }
+    } else {
+        if (sync_device(t)) { delete r; return nullptr; }
+        if (pct_radius_indices_q64(t->cloud, q, range, hits.data(), n, &nh) != PCT_OK) { complain("kd_nearest_range"); delete r; return nullptr; }
+    }
     kdres *out = build_range_result(t, q, range, hits.data(), nh);
     delete r;
     return out;
 }
 struct kdres *kd_nearest_rangef(struct kdtree *t, const float *q, float range)
 {
-    const double w[3] = { q[0], q[1], q[2] };
+    double w[kMaxDim];
+    for (int i = 0; i < t->dim; i++) w[i] = q[i];
     return kd_nearest_range(t, w, range);
 }
 struct kdres *kd_nearest_range3(struct kdtree *t, double x, double y, double z, double range)
 {
+    if (t->dim > 3) return three_only("kd_nearest_range3"), nullptr;
     const double w[3] = { x, y, z };
     return kd_nearest_range(t, w, range);
 }
 struct kdres *kd_nearest_range3f(struct kdtree *t, float x, float y, float z, float range)
 {
+    if (t->dim > 3) return three_only("kd_nearest_range3f"), nullptr;
     const double w[3] = { x, y, z };
     return kd_nearest_range(t, w, range);
 }
@@ -418,21 +502,21 @@ void *kd_res_item(struct kdres *r, double *pos)
 {
     if (!r || r->cursor >= r->items.size()) return nullptr;
     const int32_t n = r->items[r->cursor];
-    if (pos) std::memcpy(pos, &r->tree->pos[3 * (size_t)n], 3 * sizeof(double));
+    if (pos) std::memcpy(pos, &r->tree->pos[(size_t)r->tree->dim * n], (size_t)r->tree->dim * sizeof(double));
     return r->tree->data[n];
 }
 void *kd_res_itemf(struct kdres *r, float *pos)
 {
     if (!r || r->cursor >= r->items.size()) return nullptr;
     const int32_t n = r->items[r->cursor];
-    if (pos) for (int i = 0; i < 3; i++) pos[i] = (float)r->tree->pos[3 * (size_t)n + i];
+    if (pos) for (int i = 0; i < r->tree->dim; i++) pos[i] = (float)r->tree->pos[(size_t)r->tree->dim * n + i];
     return r->tree->data[n];
 }
 // kdtree.c:666-684: tests the pointee, never returns the payload -- kept as is
 void *kd_res_item3(struct kdres *r, double *x, double *y, double *z)
 {
-    if (r && r->cursor < r->items.size()) {
-        const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
+    if (r && r->cursor < r->items.size() && r->tree->dim >= 3) {         // (the reference reads three coordinates whatever the dimension)
+        const double *p = &r->tree->pos[(size_t)r->tree->dim * r->items[r->cursor]];
         if (*x) *x = p[0];
         if (*y) *y = p[1];
         if (*z) *z = p[2];
@@ -441,8 +525,8 @@ void *kd_res_item3(struct kdres *r, double *x, double *y, double *z)
 }
 void *kd_res_item3f(struct kdres *r, float *x, float *y, float *z)
 {
-    if (r && r->cursor < r->items.size()) {
-        const double *p = &r->tree->pos[3 * (size_t)r->items[r->cursor]];
+    if (r && r->cursor < r->items.size() && r->tree->dim >= 3) {
+        const double *p = &r->tree->pos[(size_t)r->tree->dim * r->items[r->cursor]];
         if (*x) *x = (float)p[0];
         if (*y) *y = (float)p[1];
         if (*z) *z = (float)p[2];
@@ -459,14 +543,14 @@ int kdx_size(struct kdtree *t) { return t ? (int)t->count() : 0; }
 void *kdx_node_data(struct kdtree *t, int32_t node) { return (t && node >= 0 && node < t->count()) ? t->data[node] : nullptr; }
 int kdx_node_pos(struct kdtree *t, int32_t node, double pos[3])
 {
-    if (!t || node < 0 || node >= t->count()) return -1;
+    if (!t || t->dim != 3 || node < 0 || node >= t->count()) return -1;
     std::memcpy(pos, &t->pos[3 * (size_t)node], 3 * sizeof(double));
     return 0;
 }
 
 int kdx_nearestf_batch(struct kdtree *t, const float *pos, int k, int32_t *node_out)
 {
-    if (!t || k < 0 || (k > 0 && (!pos || !node_out))) return -1;
+    if (!t || t->generic || k < 0 || (k > 0 && (!pos || !node_out))) return -1;      // fp32 3-D trees only
     if (t->count() == 0) { for (int i = 0; i < k; i++) node_out[i] = -1; return 0; }
     if (sync_device(t)) return -1;
     std::vector<double> q((size_t)3 * k), d2((size_t)k);
@@ -480,7 +564,7 @@ int kdx_nearestf_batch(struct kdtree *t, const float *pos, int k, int32_t *node_
 int kdx_range_candidates_batch(struct kdtree *t, const float *pos, const float *range, int k, uint32_t *ids, int cap_per_query,
                                int32_t *counts)
 {
-    if (!t || k < 0 || (k > 0 && (!pos || !range || !ids || !counts)) || cap_per_query <= 0) return -1;
+    if (!t || t->generic || k < 0 || (k > 0 && (!pos || !range || !ids || !counts)) || cap_per_query <= 0) return -1;
     for (int i = 0; i < k; i++) counts[i] = 0;
     if (t->count() == 0 || k == 0) return 0;
     if (sync_device(t)) return -1;
@@ -498,7 +582,7 @@ int kdx_range_candidates_batch(struct kdtree *t, const float *pos, const float *
 
 int kdx_set_node_aux(struct kdtree *t, int32_t node, const double aux[4])
 {
-    if (!t || node < 0 || node >= t->count() || !aux) return -1;
+    if (!t || t->generic || node < 0 || node >= t->count() || !aux) return -1;
     std::memcpy(&t->aux[4 * (size_t)node], aux, 4 * sizeof(double));
     if (node < t->synced && t->aux_mapped) std::memcpy(t->aux_mapped + 4 * (size_t)node, aux, 4 * sizeof(double));   // plain store into mapped memory
     return 0;
@@ -507,7 +591,7 @@ int kdx_set_node_aux(struct kdtree *t, int32_t node, const double aux[4])
 int kdx_expand_batch(struct kdtree *t, pct_cloud *obstacles, const pct_inflate_params *prm, const double *samples, int k, int cap_per_query,
                      pct_expand_result *out, uint32_t *ids)
 {
-    if (!t || !obstacles || !prm || k < 0 || (k > 0 && (!samples || !out || !ids)) || cap_per_query <= 0) return -1;
+    if (!t || t->generic || !obstacles || !prm || k < 0 || (k > 0 && (!samples || !out || !ids)) || cap_per_query <= 0) return -1;
     if (k == 0) return 0;
     if (t->count() > 65536) return -1;                      // the fused kernel serves host-mapped node sets
     if (sync_device(t)) return -1;
@@ -518,6 +602,7 @@ int kdx_expand_batch(struct kdtree *t, pct_cloud *obstacles, const pct_inflate_p
 
 struct kdres *kdx_range_from_candidates(struct kdtree *t, const float *pos, float range, const uint32_t *ids, int n_ids, int32_t n_snapshot)
 {
+    if (!t || t->dim != 3) return nullptr;
     const double q[3] = { pos[0], pos[1], pos[2] };
     const double rng = range, r2 = rng * rng;
     std::vector<uint32_t> hits(ids, ids + n_ids);

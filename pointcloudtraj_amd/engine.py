@@ -84,6 +84,15 @@ def lib():
         L.pct_cloud_drop_grid.argtypes = [vp]
         L.pct_cloud_has_grid.argtypes = [vp]
         L.pct_cloud_grid_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i64)]
+        L.pct_nodeset_create.argtypes = [C.c_int, i64, C.POINTER(vp)]
+        L.pct_nodeset_destroy.argtypes = [vp]
+        L.pct_nodeset_clear.argtypes = [vp]
+        L.pct_nodeset_size.argtypes = [vp]
+        L.pct_nodeset_size.restype = i64
+        L.pct_nodeset_dim.argtypes = [vp]
+        L.pct_nodeset_append.argtypes = [vp, C.POINTER(C.c_double), i64]
+        L.pct_nodeset_nearest.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+        L.pct_nodeset_radius_indices_r2.argtypes = [vp, C.POINTER(C.c_double), C.c_double, vp, i64, C.POINTER(i64)]
         L.pct_nn_batch.argtypes = [vp, f32p, i64, u32p, f64p]
         L.pct_nn_batch_algo.argtypes = [vp, i32, f32p, i64, u32p, f64p]
         L.pct_radius_count_batch.argtypes = [vp, f32p, f32p, i64, u32p]

@@ -117,3 +117,58 @@ class KDTree:
         assert len(out) == self.L.kd_res_size(rs)
         self.L.kd_res_free(rs)
         return np.asarray(out, np.int32)
+
+
+class KDTreeN:
+    """kd_* on a tree of any dimension with double positions (kd_create(k), kd_insert, kd_nearest, kd_nearest_range);
+    payload of row i is (void*)(i+1)."""
+
+    def __init__(self, dim: int):
+        self.L = lib()
+        self.dim = int(dim)
+        self.h = self.L.kd_create(self.dim)
+        if not self.h:
+            raise RuntimeError(f"kd_create({dim}) failed")
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.kd_free(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def insert(self, rows):
+        rows = np.ascontiguousarray(rows, np.float64).reshape(-1, self.dim)
+        dp = C.POINTER(C.c_double)
+        for p in rows:
+            if self.L.kd_insert(self.h, p.ctypes.data_as(dp), C.c_void_p(self.n + 1)):
+                raise MemoryError
+            self.n += 1
+
+    def nearest(self, q):
+        q = np.ascontiguousarray(q, np.float64).reshape(-1, self.dim)
+        ids = np.empty(len(q), np.int32)
+        pos = np.empty((len(q), self.dim), np.float64)
+        dp = C.POINTER(C.c_double)
+        for i, qq in enumerate(q):
+            r = self.L.kd_nearest(self.h, qq.ctypes.data_as(dp))
+            if not r:
+                raise RuntimeError("kd_nearest returned NULL")
+            d = self.L.kd_res_item(r, pos[i].ctypes.data_as(dp))
+            ids[i] = int(d or 0) - 1
+            self.L.kd_res_free(r)
+        return ids, pos
+
+    def range_ids(self, q, r):
+        q = np.ascontiguousarray(q, np.float64).reshape(self.dim)
+        rs = self.L.kd_nearest_range(self.h, q.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(r))
+        if not rs:
+            raise RuntimeError("kd_nearest_range returned NULL")
+        out = []
+        while not self.L.kd_res_end(rs):
+            out.append(int(self.L.kd_res_item_data(rs) or 0) - 1)
+            self.L.kd_res_next(rs)
+        assert len(out) == self.L.kd_res_size(rs)
+        self.L.kd_res_free(rs)
+        return np.asarray(out, np.int32)

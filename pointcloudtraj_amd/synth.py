@@ -36,6 +36,13 @@ def uniform01_f32(seed: int, n: int, offset: int = 0) -> np.ndarray:
     return ((splitmix64(seed, n, offset) >> np.uint64(40)).astype(np.float32)) * np.float32(2.0 ** -24)
 
 
+def uniform_rows_f64(seed: int, n: int, dim: int, lo: float, hi: float) -> np.ndarray:
+    """(n, dim) doubles uniform in [lo, hi) carrying 48 random bits each: almost none of them is an fp32 value."""
+    a = uniform01_f32(seed, n * dim).astype(np.float64)
+    b = uniform01_f32(seed + 7919, n * dim).astype(np.float64)
+    return (lo + (a + b * 2.0 ** -24) * (hi - lo)).reshape(n, dim)
+
+
 def uniform_points(seed: int, n: int, lo: float, hi: float, offset: int = 0) -> np.ndarray:
     """(n,3) fp32 points uniform in [lo,hi)^3; element k of the stream feeds coordinate k%3 of point k//3."""
     u = uniform01_f32(seed, 3 * n, 3 * offset).reshape(n, 3)

@@ -9,6 +9,9 @@ What is recorded, and from which implementation:
       outputs of the REFERENCE's own Utils/kdtree/src/kdtree.c (compiled unmodified into
       oracle/_ref/libkdtree_ref.so) driven through its public kd_* API.  These pin the
       oracle port (tests/test_oracle_golden.py) and, on the GPU, the HIP path.
+  kd_general_k.npz
+      the same library through kd_create(k) for k = 1, 2, 3 (doubles fp32 cannot hold), 4, 5, 7, 17: nearest ids (the walk's winner
+      on ties) and range ids in iteration order.
   binomials.npz
       the 13 x 13 table c(n, k) of the REFERENCE's own Planner/src/binomial_coefs.cpp (the one planner source that compiles
       stand-alone; oracle/_ref/libbinomial_ref.so).  Pins the three ways the oracle and the two ways the device write "n choose k".
@@ -298,6 +301,71 @@ def gen_bezier():
     P.close()
 
 
+def general_k_cases():
+    """(name, dim, rows, queries, radii): trees of other dimensions and of doubles fp32 cannot hold (kdtree.c:112-131, 167-209)"""
+    out = []
+    # doubles with 48 random bits
+    for name, dim, n, seed in (("k2", 2, 600, 11), ("k3_f64", 3, 700, 12), ("k7", 7, 500, 13), ("k17", 17, 200, 14)):
+        rows = synth.uniform_rows_f64(seed, n, dim, 0.0, 10.0)
+        q = synth.uniform_rows_f64(seed + 100, 48, dim, 0.0, 10.0)
+        # radii that catch 1 .. 24 rows: a little beyond the distance of the m-th nearest row (any double serves as a radius)
+        dist = np.sqrt(((rows[None, :, :] - q[:, None, :]) ** 2).sum(-1))
+        rad = np.sort(dist, axis=1)[np.arange(48), np.arange(48) % 24] * 1.001
+        out.append((name, dim, rows, q, rad))
+    # one dimension, duplicates
+    rows = np.round(synth.uniform_rows_f64(15, 80, 1, 0.0, 12.0))
+    q = np.concatenate([np.arange(0, 12, 0.5), [3.25, 7.75]]).reshape(-1, 1)
+    out.append(("k1_dups", 1, rows, q, np.full(len(q), 1.5)))
+    # lattice {0,1,2}^5 (ties everywhere, |dx| == range on split planes), every point once, shuffled; queries on and between the points
+    g = np.arange(3, dtype=np.float64)
+    rows = np.stack(np.meshgrid(g, g, g, g, g, indexing="ij"), -1).reshape(-1, 5)
+    rows = rows[synth.shuffled_order(16, len(rows))]
+    q = np.round(synth.uniform_rows_f64(116, 40, 5, 0.0, 4.0)) / 2.0
+    out.append(("k5_lattice", 5, rows, q, np.where(np.arange(len(q)) % 2 == 0, 1.0, 1.5)))
+    # a 3-D tree that starts with fp32 values and is handed an unrepresentable double halfway (the drop-in migrates it)
+    rows = synth.uniform_points(17, 400, 0, 10).astype(np.float64)
+    rows[200:] = synth.uniform_rows_f64(18, 200, 3, 0.0, 10.0)
+    q = synth.uniform_rows_f64(117, 48, 3, 0.0, 10.0)
+    out.append(("k3_mixed", 3, rows, q, 0.5 + synth.uniform01_f32(217, 48).astype(np.float64) * 2.0))
+    return out
+
+
+def gen_general_k():
+    print("general-k fixtures (reference kdtree.c through kd_create(k) / kd_insert / kd_nearest / kd_nearest_range):")
+    kw = {}
+    names = []
+    for name, dim, rows, q, rad in general_k_cases():
+        R = O.RefKDN(dim)
+        R.insert(rows)
+        nn = R.nearest(q)
+        ids, offs = [], [0]
+        for i in range(len(q)):
+            a = R.range_ids(q[i], float(rad[i]))
+            ids.append(a)
+            offs.append(offs[-1] + len(a))
+        R.close()
+        names.append(name)
+        kw.update({f"{name}_rows": rows, f"{name}_queries": q, f"{name}_radii": rad, f"{name}_nn": nn,
+                   f"{name}_range_ids": np.concatenate(ids).astype(np.int32), f"{name}_range_offsets": np.asarray(offs, np.int64)})
+    # a tree beyond the drop-in's host-scan size: rows regenerated from the seed, answers stored
+    dim, n = 4, 20000
+    rows = synth.uniform_rows_f64(19, n, dim, 0.0, 50.0)
+    q = synth.uniform_rows_f64(119, 64, dim, 0.0, 50.0)
+    rad = 2.0 + synth.uniform01_f32(219, 64).astype(np.float64) * 6.0
+    R = O.RefKDN(dim)
+    R.insert(rows)
+    nn = R.nearest(q)
+    ids, offs = [], [0]
+    for i in range(len(q)):
+        a = R.range_ids(q[i], float(rad[i]))
+        ids.append(a)
+        offs.append(offs[-1] + len(a))
+    R.close()
+    kw.update({"k4_big_seed_dim_n": np.asarray([19, dim, n], np.int64), "k4_big_queries": q, "k4_big_radii": rad, "k4_big_nn": nn,
+               "k4_big_range_ids": np.concatenate(ids).astype(np.int32), "k4_big_range_offsets": np.asarray(offs, np.int64)})
+    save("kd_general_k.npz", cases=np.asarray(names), **kw)
+
+
 def gen_binomials():
     print("binomial table of the reference's Planner/src/binomial_coefs.cpp (compiled into oracle/_ref/libbinomial_ref.so):")
     L = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libbinomial_ref.so"))
@@ -312,7 +380,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "binomials":      # only the table (the other fixtures stay as committed)
         gen_binomials()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "general_k":      # only the general-k fixture
+        gen_general_k()
+        sys.exit(0)
     gen_binomials()
+    gen_general_k()
     gen_nn()
     gen_range()
     gen_api_edges()

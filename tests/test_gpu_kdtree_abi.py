@@ -125,7 +125,61 @@ def test_kd_api_edges(K):
     assert order == list(g["destructor_order"])
     assert int(L.kd_nearestf(t, q) is None) == int(g["after_clear_nn_null"]) == 1
     L.kd_free(t)
-    assert L.kd_create(2) is None          # documented limitation: k == 3 only
+    assert L.kd_create(0) is None and L.kd_create(1025) is None      # documented limits: 1 <= k <= 1024
+    t5 = L.kd_create(5)
+    assert t5 is not None and L.kd_insert3(t5, 1.0, 2.0, 3.0, None) == -1 and L.kd_nearest3(t5, 1.0, 2.0, 3.0) is None   # x,y,z forms: <= 3 dimensions
+    L.kd_free(t5)
+
+
+@pytest.mark.parametrize("name", ["k2", "k3_f64", "k7", "k17", "k1_dups", "k5_lattice", "k3_mixed", "k4_big"])
+def test_kd_general_k_golden(K, name):
+    """kd_create(k) for k = 1 .. 17 and doubles fp32 cannot hold (kdtree.c:112-131, 167-209): the drop-in keeps such trees as fp64
+    columns in HBM (csrc/nodeset.hip) and returns the compiled reference's nearest node -- its walk's winner on exact ties
+    (k5_lattice, k1_dups) -- and its range ITERATION order.  k3_mixed starts as an fp32 tree and is handed an unrepresentable double
+    halfway; k4_big (20 000 rows) is answered by the kernels under either dispatch."""
+    from test_oracle_golden import general_k_case
+    dim, rows, q, rad, nn, ids, offs = general_k_case(load_golden("kd_general_k.npz"), name)
+    t = K.KDTreeN(dim)
+    t.insert(rows)
+    got, pos = t.nearest(q)
+    assert np.array_equal(got, nn)
+    assert np.array_equal(pos, rows[nn])                              # kd_res_item: the stored doubles, all k of them
+    for i in range(len(q)):
+        assert np.array_equal(t.range_ids(q[i], float(rad[i])), ids[offs[i]:offs[i + 1]]), f"query {i}"
+    t.close()
+
+
+def test_nodeset_abi_direct():
+    """include/pct_engine.h "node sets": lowest node number + tie count at the minimum, ascending hit lists, growth, clear"""
+    from pointcloudtraj_amd import engine as E
+    E.init(0)
+    L = E.lib()
+    dp = C.POINTER(C.c_double)
+    h = C.c_void_p()
+    assert L.pct_nodeset_create(4, 2, C.byref(h)) == 0
+    idx, ties, d2, n = C.c_uint32(), C.c_uint32(), C.c_double(), C.c_int64()
+    q = np.float64([1, 1, 1, 1])
+    assert L.pct_nodeset_nearest(h, q.ctypes.data_as(dp), C.byref(idx), C.byref(d2), C.byref(ties)) == 0
+    assert idx.value == 0xFFFFFFFF and d2.value == np.inf and ties.value == 0
+    rng = np.random.default_rng(5)
+    rows = np.round(rng.random((5000, 4)) * 3.0)                      # integer lattice: many exact ties
+    for a in range(0, 5000, 1237):                                    # several appends across two capacity growths
+        blk = np.ascontiguousarray(rows[a:a + 1237])
+        assert L.pct_nodeset_append(h, blk.ctypes.data_as(dp), len(blk)) == 0
+    assert L.pct_nodeset_size(h) == 5000 and L.pct_nodeset_dim(h) == 4
+    for qq in (np.float64([1, 1, 1, 1]), np.float64([0.5, 2.5, 1.0, 3.0]), np.float64([9, 9, 9, 9])):
+        d = ((rows - qq) ** 2)
+        s = ((d[:, 0] + d[:, 1]) + d[:, 2]) + d[:, 3]
+        assert L.pct_nodeset_nearest(h, qq.ctypes.data_as(dp), C.byref(idx), C.byref(d2), C.byref(ties)) == 0
+        assert d2.value == s.min() and idx.value == int(np.flatnonzero(s == s.min())[0]) and ties.value == int((s == s.min()).sum())
+        out = np.empty(5000, np.uint32)
+        r2 = 2.25
+        assert L.pct_nodeset_radius_indices_r2(h, qq.ctypes.data_as(dp), C.c_double(r2), out.ctypes.data_as(C.c_void_p), 5000, C.byref(n)) == 0
+        assert np.array_equal(out[:n.value], np.flatnonzero(s <= r2).astype(np.uint32))
+        assert L.pct_nodeset_radius_indices_r2(h, qq.ctypes.data_as(dp), C.c_double(r2), out.ctypes.data_as(C.c_void_p), 3, C.byref(n)) == 0
+        assert n.value == int((s <= r2).sum())                        # the count is reported whatever the capacity
+    assert L.pct_nodeset_clear(h) == 0 and L.pct_nodeset_size(h) == 0
+    assert L.pct_nodeset_destroy(h) == 0
 
 
 def test_cpp_client_of_both_libraries():

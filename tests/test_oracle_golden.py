@@ -55,6 +55,33 @@ def test_port_range_order_matches_reference(oracle, name):
     assert np.array_equal(cnt, np.diff(offs).astype(np.int32))
 
 
+GENERAL_K = ["k2", "k3_f64", "k7", "k17", "k1_dups", "k5_lattice", "k3_mixed", "k4_big"]
+
+
+def general_k_case(g, name):
+    """(dim, rows, queries, radii, nn, range ids, offsets) of one case of kd_general_k.npz"""
+    if name == "k4_big":
+        seed, dim, n = (int(v) for v in g["k4_big_seed_dim_n"])
+        rows = synth.uniform_rows_f64(seed, n, dim, 0.0, 50.0)
+    else:
+        rows = g[name + "_rows"]
+        dim = rows.shape[1]
+    return dim, rows, g[name + "_queries"], g[name + "_radii"], g[name + "_nn"], g[name + "_range_ids"], g[name + "_range_offsets"]
+
+
+@pytest.mark.parametrize("name", GENERAL_K)
+def test_port_general_k_matches_reference(oracle, name):
+    """kd_create(k) for k = 1 .. 17 with double positions (kdtree.c:112-131, 167-209): the restatement returns the compiled
+    reference's nearest node (its walk's winner on the lattice's and the duplicates' exact ties) and its range iteration order"""
+    dim, rows, q, rad, nn, ids, offs = general_k_case(load_golden("kd_general_k.npz"), name)
+    P = oracle.PortKDN(dim)
+    P.insert(rows)
+    assert np.array_equal(P.nearest(q), nn)
+    for i in range(len(q)):
+        assert np.array_equal(P.range_ids(q[i], float(rad[i])), ids[offs[i]:offs[i + 1]]), f"query {i}"
+    P.close()
+
+
 def test_lattice_reference_misses_boundary_hits():
     """Known quirk (kdtree.c:283): the far side is pruned unless fabs(dx) < range, so points
     at distance exactly == range can be dropped depending on tree shape.  The fixture
