@@ -72,17 +72,25 @@ def measured_counters(kernel: str, pattern: str = "*_bench_pmc.json", threads: i
 
 def bound_from_counters(cnt, kernel_ms=None):
     """what limits the kernel by the committed counters: 'hbm' when the fabric traffic it causes (2 x FETCH_SIZE + WRITE_SIZE) moves at
-    half the HBM peak or more during the kernel's time -- the waves then wait on bandwidth; 'latency' when they wait (SQ_WAIT_ANY over half
-    of SQ_WAVE_CYCLES) while the traffic stays below that: dependent round trips; else 'valu'.  (None, None) without counters."""
+    half the HBM peak or more during the kernel's time -- the waves then wait on bandwidth; 'valu' when the vector ALUs issue during
+    60 % or more of the kernel's cycles (a wave64 instruction occupies its SIMD's 16 lanes for 4 cycles: busy = 4 x SQ_ACTIVE_INST_VALU /
+    (1024 SIMDs x cycles), cycles = GRBM_GUI_ACTIVE / 8 XCDs) -- the waves' own waiting (SQ_WAIT_ANY) is then hidden behind the other
+    waves of the SIMD; 'latency' when neither holds and the waves wait more than half of their cycles: dependent round trips.
+    (None, None) without counters."""
     if not cnt or "SQ_WAVE_CYCLES" not in cnt:
         return None, None
     wait = cnt.get("SQ_WAIT_ANY", 0.0) / max(cnt["SQ_WAVE_CYCLES"], 1.0)
     traffic = cnt.get("derived_hbm_traffic_bytes_per_launch")
     tfrac = (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic and kernel_ms else None
+    cycles = cnt.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    valu_busy = (4.0 * cnt.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * cycles)) if cycles > 0 else None
     detail = {"wait_fraction_of_wave_cycles": wait, "traffic_fraction_of_hbm_peak": tfrac, "l2_hit_rate": cnt.get("derived_l2_hit_rate"),
-              "valu_instructions_per_wave": (cnt.get("SQ_INSTS_VALU", 0.0) / cnt["SQ_WAVES"]) if cnt.get("SQ_WAVES") else None}
+              "valu_instructions_per_wave": (cnt.get("SQ_INSTS_VALU", 0.0) / cnt["SQ_WAVES"]) if cnt.get("SQ_WAVES") else None,
+              "valu_issue_busy_fraction": valu_busy}
     if tfrac is not None and tfrac >= 0.5:
         return "hbm", detail
+    if valu_busy is not None and valu_busy >= 0.6:
+        return "valu", detail
     return ("latency" if wait > 0.5 else "valu"), detail
 
 

@@ -382,9 +382,10 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
     if ((size_t)n > *sorted_cap) {
         dev_free(*sorted);
         *sorted_cap = 0;
-        PCTCHK(dev_alloc(sorted, (size_t)n));
+        PCTCHK(dev_alloc(sorted, (size_t)n + kGridPad));         // + the inert records behind the last one (gb_pad_kernel)
         *sorted_cap = (size_t)n;
     }
+    gb_pad_kernel<<<1, 64, 0, s>>>(*sorted + n);
     // ---- two-level counting sort on LDS histograms (gridbuild.hpp): no device-scope atomic per point ----
     static const bool lds_build = [] { const char *e = std::getenv("PCT_LDS_GRID_BUILD"); return e ? std::atoi(e) != 0 : true; }();
     // slabs of 2^s1 consecutive cells, sized for ~2-6 k points each (level 2 then holds a whole slab in LDS), at most kGbMaxSlabs;

@@ -37,6 +37,15 @@ constexpr int kGbCheckSlots = 64;      // blocks add into slot blockIdx & 63 (th
 
 // zeroes the build's counters (a kernel of this library on the build's stream, not a runtime memset: one thing less between the
 // launches that is not ours)
+// kGridPad inert records behind the last cell-sorted one: the open-ended screening of the dense batch kernel (kernels.hpp
+// coop_screen_rows<.., OPEN>) reads up to 15 records past the start of any run, i.e. past the end of the array for the last cells.
+// +inf coordinates give a distance of +inf to every finite query: never a minimum, never inside a radius.
+constexpr uint32_t kGridPad = 16;
+__global__ void gb_pad_kernel(float4 *__restrict__ tail)
+{
+    if (threadIdx.x < kGridPad) tail[threadIdx.x] = make_float4(__builtin_huge_valf(), __builtin_huge_valf(), __builtin_huge_valf(), __uint_as_float(0xFFFFFFFFu));
+}
+
 __global__ __launch_bounds__(256) void gb_zero_kernel(uint32_t *__restrict__ a, uint32_t n, GbCheck *__restrict__ chk)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

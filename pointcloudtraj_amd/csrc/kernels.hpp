@@ -1629,7 +1629,14 @@ __device__ __forceinline__ void coop_scan_cube_or_shell(const GridDesc &G, const
 // runner-up lies outside the fp32 error band the minimum IS the exact winner and is evaluated once in fp64, otherwise the
 // runs are rescanned in exact arithmetic.  All NR rows are requested before any is consumed (the kernel is bound by
 // dependent memory round trips: one for the bounds, one for the points).  Leaves (bd, bi) = (+inf, none) for empty runs.
-template <int NR, int DEPTH>
+// OPEN = true (A/B switch PCT_AB_OPEN_STAGE0, NOT the default): the 8 * DEPTH slots behind a run's first record are read and
+// screened whatever the run's length -- what lies behind a short run are the records of the following cells, real points of the cloud
+// (or the +inf pad records behind the last one, gb_pad_kernel), and the nearest neighbour over a superset of the block is still a
+// valid candidate.  It removes the clamp, the empty-run select and the validity masks (~4 of ~17 vector instructions per slot) -- and
+// measured SLOWER on the headline step: 0.146 ms (72 VGPRs, 7 waves) / 0.132 ms (77 VGPRs, 6 waves) / 0.21 ms (64 VGPRs: 60 B of
+// scratch) against 0.120 ms masked (profiles/r03_ab_open_stage0.txt).  The clamp is what keeps the lanes beyond a run on the run's last
+// cache line; without it every run costs two full lines more often, and this kernel pays for lines before it pays for instructions.
+template <int NR, int DEPTH, bool OPEN = false>
 __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts, const uint32_t (&rs)[NR], const uint32_t (&re)[NR],
                                                  uint32_t sub, float qxf, float qyf, float qzf, double qx, double qy, double qz,
                                                  double &bd, uint32_t &bi)
@@ -1643,7 +1650,7 @@ __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts,
         const uint32_t a = rs[k], b = re[k];
         const uint32_t last = b > a ? b - 1 : 0u;               // empty row: read slot 0, masked below
 #pragma unroll
-        for (int j = 0; j < DEPTH; j++) P[k][j] = pts[min(a + sub + kCoop * j, last)];
+        for (int j = 0; j < DEPTH; j++) P[k][j] = pts[OPEN ? a + sub + kCoop * j : min(a + sub + kCoop * j, last)];
     }
 #pragma unroll
     for (int k = 0; k < NR; k++) {
@@ -1653,9 +1660,9 @@ __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts,
             const uint32_t p = a + sub + kCoop * j;
             const float dx = P[k][j].x - qxf, dy = P[k][j].y - qyf, dz = P[k][j].z - qzf;
             float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-            d = (p < b) ? d : __builtin_huge_valf();
+            if (!OPEN) d = (p < b) ? d : __builtin_huge_valf();
             const bool lt = d < m1;
-            m2 = lt ? m1 : fminf(m2, d);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, d);            // second smallest of {m1 <= m2, d}
             p1 = lt ? p : p1;
             m1 = fminf(m1, d);
         }
@@ -1669,7 +1676,7 @@ __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts,
             const float dx = Pp.x - qxf, dy = Pp.y - qyf, dz = Pp.z - qzf;
             const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
             const bool lt = d < m1;
-            m2 = lt ? m1 : fminf(m2, d);
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, d);
             p1 = lt ? p : p1;
             m1 = fminf(m1, d);
         }
@@ -1687,7 +1694,7 @@ __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts,
         const float o1 = __shfl_xor(m1, off, kWave), o2 = __shfl_xor(m2, off, kWave);
         const uint32_t op = (uint32_t)__shfl_xor((int)p1, off, kWave);
         const bool lt = o1 < m1;
-        m2 = fminf(fminf(m2, o2), lt ? m1 : o1);
+        m2 = fminf(fminf(m2, o2), fmaxf(m1, o1));                // second smallest of the two sorted pairs
         p1 = lt ? op : p1;
         m1 = fminf(m1, o1);
     }
@@ -1825,7 +1832,11 @@ __device__ __forceinline__ bool coop_stage0(const GridDesc &G, const float4 *__r
 #pragma unroll
         for (int k = 0; k < 4; k++) { rs[k] = (uint32_t)__shfl((int)my_s, k, kCoop); re[k] = (uint32_t)__shfl((int)my_e, k, kCoop); }
     }
+#ifdef PCT_AB_OPEN_STAGE0          // measured slower: see coop_screen_rows
+    coop_screen_rows<4, 2, true>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+#else
     coop_screen_rows<4, 2>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
+#endif
     // Quick accept in fp32 (the six fp64 face distances below cost ~6 of the kernel's 120 us): distances to the block's faces in cell
     // units from the fractional position already at hand, the nearest one with cells behind it shortened by 1/64 cell -- far more
     // than the fp32 rounding of fx (< 2e-4 cells) plus the exact test's own 1/256 slack -- so whatever passes here passes the exact

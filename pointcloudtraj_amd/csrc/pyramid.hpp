@@ -386,6 +386,9 @@ __device__ __forceinline__ bool pyr_nn_search_fast(const GridDesc &G, int nlev, 
     uint32_t cstart = 0, ccount = 0;
     for (;;) {
         const int cl = L - 1;
+#ifdef PCT_AB_ITERSTAT
+        if (COUNT && sub == 0) npts += 1;                                 // A/B instrumentation: iterations of the walk instead of points
+#endif
         if (fetch) {
             const uint32_t pgx = (uint32_t)pyr_dim(G.gx, L), pgy = (uint32_t)pyr_dim(G.gy, L);
             const float4 *n = reinterpret_cast<const float4 *>(nodes + (s_off[cl] + 8u * (((uint32_t)Z * pgy + (uint32_t)Y) * pgx + (uint32_t)X) + sub));
@@ -446,7 +449,9 @@ __device__ __forceinline__ bool pyr_nn_search_fast(const GridDesc &G, int nlev, 
             }
             gm = group8_min_f32(B.m1);
             lim = (gm * (1.0f + 0x1p-19f) + 0x1p-90f) * (1.0f + 0x1p-20f);
+#ifndef PCT_AB_ITERSTAT
             if (COUNT && sub == 0) { npts += n; nruns += 1; }
+#endif
             fetch = false;
             continue;
         }
@@ -506,7 +511,9 @@ __device__ __forceinline__ void pyr_answer(const GridDesc &G, const PyrDesc &PD,
         const uint32_t row = cell_lin(G, 0, (ri & 1) ? yb : ya, (ri >> 1) ? zb : za);
         const uint32_t a = cell_start[row + xa], b = cell_start[row + xb + 1];
         const uint32_t my_s = a, my_e = ok ? b : a;
+#ifndef PCT_AB_ITERSTAT
         if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
+#endif
         rs[0] = dpp_u32<kDppQuadBcast0>(my_s); rs[1] = dpp_u32<kDppQuadBcast1>(my_s); rs[2] = dpp_u32<kDppQuadBcast2>(my_s); rs[3] = dpp_u32<kDppQuadBcast3>(my_s);
         re[0] = dpp_u32<kDppQuadBcast0>(my_e); re[1] = dpp_u32<kDppQuadBcast1>(my_e); re[2] = dpp_u32<kDppQuadBcast2>(my_e); re[3] = dpp_u32<kDppQuadBcast3>(my_e);
     }
@@ -588,6 +595,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_PYR_
     uint32_t npts = 0, nruns = 0, nnodes = 0;
     if (slot < Q)                                     // uniform within a group of 8 lanes
         pyr_answer<COUNT, FAST>(G, PD, s_off, nodes, hint, pts, cell_start, q, index_base, qsorted, slot, sub, out_idx, out_d2, sorted_out, todo, npts, nruns, nnodes);
+#ifdef PCT_AB_ITERSTAT
+    if (COUNT) {                                      // `runs` := 8 x the longest walk of the wave (what the wave pays), `points` := the walks' own lengths
+        uint32_t m = npts;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, kWave));
+        nruns = (threadIdx.x & 63) == 0 ? 8u * m : 0u;
+    }
+#endif
     pyr_commit_work<COUNT>(npts, nruns, nnodes, work);
 }
 

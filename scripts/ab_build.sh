@@ -4,4 +4,4 @@
 TAG=$1; shift
 mkdir -p pointcloudtraj_amd/lib/variants
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -Wall -Wno-unused-function -Iinclude "$@" \
-  -o pointcloudtraj_amd/lib/variants/libpct_engine_$TAG.so pointcloudtraj_amd/csrc/engine.hip pointcloudtraj_amd/csrc/voxel.hip pointcloudtraj_amd/csrc/traj.hip
+  -o pointcloudtraj_amd/lib/variants/libpct_engine_$TAG.so pointcloudtraj_amd/csrc/engine.hip pointcloudtraj_amd/csrc/voxel.hip pointcloudtraj_amd/csrc/traj.hip pointcloudtraj_amd/csrc/nodeset.hip
