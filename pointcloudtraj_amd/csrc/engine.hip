@@ -154,6 +154,8 @@ struct pct_cloud {
     size_t cells_cap = 0;
     float4 *sorted = nullptr;
     size_t sorted_cap = 0;
+    uint4 *blocks = nullptr;                 // block table (kernels.hpp block_corner_kernel): 2 x uint4 per lattice corner
+    size_t blocks_cap = 0;
     BinDesc B{};
     // optional coarser copies of the index (clouds with sparse occupancy), see kernels.hpp CoarseLevels
     CoarseLevels C{};
@@ -1347,6 +1349,7 @@ int pct_cloud_destroy(pct_cloud *c)
     if (c->h_eout) (void)hipHostFree(c->h_eout);
     if (c->h_bpos) (void)hipHostFree(c->h_bpos);
     dev_free(c->x); dev_free(c->y); dev_free(c->z); dev_free(c->d_stage); dev_free(c->gb_tmp); dev_free(c->gb_small);
+    dev_free(c->blocks);
     dev_free(c->cell_start); dev_free(c->sorted); dev_free(c->bin_start); dev_free(c->bin_fill); dev_free(c->bin_tiles);
     for (int l = 0; l < kMaxCoarse; l++) { dev_free(c->coarse_cell_start[l]); dev_free(c->coarse_sorted[l]); }
     dev_free(c->d_qbin); dev_free(c->d_perm); dev_free(c->d_qsorted); dev_free(c->d_sorttmp); dev_free(c->d_sortkey); dev_free(c->d_sort1);
@@ -1619,6 +1622,28 @@ int pct_cloud_build_grid(pct_cloud *c, float cell_size)
     }
     G.octant_first = 1;
     if (const char *eo = std::getenv("PCT_OCTANT_FIRST")) G.octant_first = std::atoi(eo) != 0;
+    // block table for stage 0 of the dense batch kernel (kernels.hpp block_corner_kernel).  OFF by default -- measured slower on the
+    // headline step (0.126-0.131 ms against 0.120-0.121, profiles/r03_ab_block_table.txt): the 6.7 MB cell table it replaces is served
+    // by the L2s, the 56 MB of corner entries are not, and one line that misses costs more than four that hit.  PCT_BLOCK_TABLE=1
+    // (read at every build) keeps it selectable and tested.
+    G.blocks = nullptr;
+    {
+        const char *et = std::getenv("PCT_BLOCK_TABLE");
+        const bool table_on = et ? std::atoi(et) != 0 : false;
+        const uint64_t ncorners = (uint64_t)(G.gx + 1) * (uint64_t)(G.gy + 1) * (uint64_t)(G.gz + 1);
+        if (table_on && G.octant_first && !c->has_pyr && ncorners < 0x7FFFFFF0ull) {
+            if ((size_t)(2 * ncorners) > c->blocks_cap) {
+                dev_free(c->blocks);
+                c->blocks_cap = 0;
+                PCTCHK(dev_alloc(&c->blocks, (size_t)(2 * ncorners)));
+                c->blocks_cap = (size_t)(2 * ncorners);
+            }
+            block_corner_kernel<<<ceil_div((int64_t)ncorners, 256), 256, 0, s>>>(G, c->cell_start, c->blocks, (uint32_t)ncorners);
+            HIPCHK(hipGetLastError());
+            PCTCHK(note_mutation(c));            // queued, not awaited: a *_dev call on another stream waits on the event
+            G.blocks = c->blocks;
+        }
+    }
     c->G = G;
     // query bins: (2^shift)^3 cells each
     BinDesc B{};

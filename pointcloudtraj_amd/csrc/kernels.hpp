@@ -921,6 +921,9 @@ struct GridDesc {
     int gx, gy, gz;
     uint32_t ncells;
     int octant_first;          // cooperative NN: try the 2x2x2 block on the query's side before the 3x3x3 cube
+    // block table (optional, nullptr = none): for every corner (u, v, w) of the cell lattice, u in [0, gx] etc., the four x-runs of the
+    // 2x2x2 block of cells around it -- entry 2*i = the runs' first records, 2*i + 1 = one past their last (block_corner_kernel)
+    const uint4 *blocks;
 };
 
 __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g)
@@ -933,6 +936,31 @@ __device__ __forceinline__ int cell_coord(float v, float o, float inv_h, int g)
 __device__ __forceinline__ uint32_t cell_lin(const GridDesc &G, int cx, int cy, int cz)
 {
     return ((uint32_t)cz * (uint32_t)G.gy + (uint32_t)cy) * (uint32_t)G.gx + (uint32_t)cx;
+}
+
+// The block table (opt-in: PCT_BLOCK_TABLE=1; measured slower than what it replaces, see engine.hip).  Stage 0 of the batch search reads
+// the four x-runs of the 2x2x2 block of cells on the query's side of its cell: eight words of cell_start in four different rows of the
+// table = four cache lines per query, 40 % of the line look-ups of the dense batch kernel.  The block only depends on the lattice corner
+// the query is nearest to, so the build can lay the eight words of every corner side by side: one 32-byte entry, one line, no cross-lane
+// broadcast -- but a table eight times the size of cell_start, which no longer lives in the L2s.  Corner (u, v, w), u in [0, gx]: cells [max(u-1, 0), min(u, gx-1)] along x, the same along y and z; a row that
+// coincides with another one at the border of the grid is stored as an empty run (first == last), exactly as stage 0 computes it.
+__global__ __launch_bounds__(256) void block_corner_kernel(GridDesc G, const uint32_t *__restrict__ cell_start, uint4 *__restrict__ blocks, uint32_t ncorners)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncorners) return;
+    const uint32_t ux = (uint32_t)G.gx + 1u, uy = (uint32_t)G.gy + 1u;
+    const int u = (int)(i % ux), v = (int)((i / ux) % uy), w = (int)(i / (ux * uy));
+    const int xa = max(u - 1, 0), xb = min(u, G.gx - 1), ya = max(v - 1, 0), yb = min(v, G.gy - 1), za = max(w - 1, 0), zb = min(w, G.gz - 1);
+    uint32_t s[4], e[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool ok = !((r >> 1) && zb == za) && !((r & 1) && yb == ya);
+        const uint32_t row = cell_lin(G, 0, (r & 1) ? yb : ya, (r >> 1) ? zb : za);
+        s[r] = cell_start[row + xa];
+        e[r] = ok ? cell_start[row + xb + 1] : s[r];
+    }
+    blocks[2u * i] = make_uint4(s[0], s[1], s[2], s[3]);
+    blocks[2u * i + 1u] = make_uint4(e[0], e[1], e[2], e[3]);
 }
 
 // OPTIONAL coarser copies of the index (cell size x4 per level, same origin), used only by the block-per-query
@@ -1822,7 +1850,18 @@ __device__ __forceinline__ bool coop_stage0(const GridDesc &G, const float4 *__r
     const int ya = max(fy < 0.5f ? cy - 1 : cy, 0), yb = min(fy < 0.5f ? cy : cy + 1, G.gy - 1);
     const int za = max(fz < 0.5f ? cz - 1 : cz, 0), zb = min(fz < 0.5f ? cz : cz + 1, G.gz - 1);
     uint32_t rs[4], re[4];
-    {
+    if (G.blocks) {                                               // the corner's entry of the block table: one line, every lane reads it itself
+        const uint32_t u = (uint32_t)(fx < 0.5f ? cx : cx + 1), v = (uint32_t)(fy < 0.5f ? cy : cy + 1), w = (uint32_t)(fz < 0.5f ? cz : cz + 1);
+        const uint4 *ent = G.blocks + 2u * ((w * ((uint32_t)G.gy + 1u) + v) * ((uint32_t)G.gx + 1u) + u);
+        const uint4 S = ent[0], E = ent[1];
+        rs[0] = S.x; rs[1] = S.y; rs[2] = S.z; rs[3] = S.w;
+        re[0] = E.x; re[1] = E.y; re[2] = E.z; re[3] = E.w;
+        if (COUNT && sub < 4) {
+            const int ri = (int)sub;
+            const bool ok = !((ri >> 1) && zb == za) && !((ri & 1) && yb == ya);
+            npts += re[ri] - rs[ri]; nruns += ok ? 1u : 0u;
+        }
+    } else {
         const int ri = (int)sub & 3;                              // lanes 4..7 repeat lanes 0..3 (same addresses: no extra access)
         const bool ok = !((ri >> 1) && zb == za) && !((ri & 1) && yb == ya);
         const uint32_t row = cell_lin(G, 0, (ri & 1) ? yb : ya, (ri >> 1) ? zb : za);

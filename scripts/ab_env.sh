@@ -1,11 +1,8 @@
-# same-box comparison of environment switches of ONE build: scripts/ab_env.sh "NAME=VAL ..." "NAME=VAL ..." ...  (each argument one
-# variant; "-" = defaults), two rounds, wall-clock ms per 1M-query step (scripts/ab_step.py)
-cd $GRAFT_REPO_ROOT
-for round in 1 2; do
-  i=0
+# headline step under settings of ONE environment variable: bash scripts/ab_env.sh VAR v1 v2 ...   (each value twice, alternating)
+VAR=$1; shift
+for rep in 1 2; do
   for v in "$@"; do
-    i=$((i+1))
-    if [ "$v" = "-" ]; then envs=""; else envs="$v"; fi
-    echo "variant$i round$round [$v] $(env $envs timeout -k 10 200 python scripts/ab_step.py 2>&1 | tail -1)"
+    env $VAR=$v python bench.py --steps 100 --warmup 50 --stream-probe 0 --replan-probe 0 --c4-probe 0 --clustered-probe 0 --cpu-queries 0 2>/dev/null | \
+      python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$VAR=$v', 'ms_per_step %.4f kernel_ms %.4f q/s %.3e' % (d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))"
   done
 done

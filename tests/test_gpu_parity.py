@@ -566,6 +566,40 @@ def test_box_pyramid_forced_on_every_shape(E, oracle, shape, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["uniform", "lattice_ties", "thin"])
+def test_block_table_stage0_equals_the_cell_table_one(E, oracle, shape, monkeypatch):
+    """PCT_BLOCK_TABLE=1 (opt-in, read at every build): stage 0 of the dense batch kernel takes its four run bounds from the corner table
+    instead of cell_start -- the same runs, hence the same answers AND the same work counters; queries on the borders of the grid (clamped
+    corners, coinciding rows stored as empty runs) and far outside included.  Bit-exact against the exhaustive oracle."""
+    if shape == "uniform":
+        pts = synth.uniform_points(211, 200_000, 0, 40)
+    elif shape == "lattice_ties":
+        g = np.arange(0, 20, dtype=np.float32) * np.float32(0.5)
+        pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)[synth.shuffled_order(212, 8000)]
+    else:
+        pts = synth.uniform_points(213, 50_000, 0, 30); pts[:, 2] = np.float32(2.0) + pts[:, 2] * np.float32(1e-3)     # one or two cells thick
+    lo, hi = pts.min(0).astype(np.float64), pts.max(0).astype(np.float64)
+    span = np.maximum(hi - lo, 1.0)
+    u = synth.uniform01_f32(214, 3 * 30_000).reshape(-1, 3).astype(np.float64)
+    q = np.concatenate([lo - 0.2 * span + u[:24_000] * 1.4 * span, lo + (u[24_000:] - 0.5) * 30.0 * span,
+                        pts[:: max(1, len(pts) // 1500)][:1500].astype(np.float64)]).astype(np.float32)
+    bi, bd = oracle.brute_nearest_mt(pts, q)
+    work = {}
+    for table in ("0", "1"):
+        monkeypatch.setenv("PCT_BLOCK_TABLE", table)
+        monkeypatch.setenv("PCT_PYRAMID", "0")
+        c = make_cloud(E, pts, grid=True)
+        c.set_work_counters(True)
+        ig, dg = c.nn(q, E.ALGO_GRID)
+        work[table] = c.last_work()
+        c.set_work_counters(False)
+        assert np.array_equal(dg, bd), table
+        assert np.array_equal(ig.astype(np.int64), bi.astype(np.int64)), table
+        c.close()
+    assert work["0"] == work["1"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [3000, 300_000])       # express path (host-mapped id list) and the order-preserving compaction
 def test_lidar_crop_indices_distances_and_cloud(E, oracle, n):
     """camera_sensor.cpp:133-145 / 398-401: radiusSearch around the sensor + PointCloud(cloud, indices).  Checked against
