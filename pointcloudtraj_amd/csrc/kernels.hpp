@@ -1680,6 +1680,9 @@ __device__ __forceinline__ void coop_screen_rows(const float4 *__restrict__ pts,
 #pragma unroll
         for (int j = 0; j < DEPTH; j++) P[k][j] = pts[OPEN ? a + sub + kCoop * j : min(a + sub + kCoop * j, last)];
     }
+#ifdef PCT_AB_SCHED_BARRIER
+    __builtin_amdgcn_sched_barrier(0);                           // nothing moves across: every load above is issued before the first use below
+#endif
 #pragma unroll
     for (int k = 0; k < NR; k++) {
         const uint32_t a = rs[k], b = re[k];
@@ -2017,10 +2020,17 @@ __device__ __forceinline__ void coop_finish_shells(const GridDesc &G, const floa
 }
 
 template <bool COUNT, bool WAVE = false>
+// Occupancy target 7 waves per SIMD, as minimum AND maximum: with 8 allowed the scheduler keeps the kernel at 64 VGPRs by issuing the
+// eight record loads of stage 0 two at a time (four dependent round trips); capped at 7 it takes 72 VGPRs and issues all eight before the
+// first use.  Headline step 0.1198-0.1210 -> 0.1163-0.1179 ms (6 waves: 0.122, 5: 0.134; profiles/r03_ab_occupancy_cap.txt).  Raising
+// only the minimum (round 2's "7 waves" experiment) never changed the code: the scheduler still aimed for 8.
 #ifndef PCT_AB_COOP_WAVES
-#define PCT_AB_COOP_WAVES 8
+#define PCT_AB_COOP_WAVES 7
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_COOP_WAVES, 8))) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
+#ifndef PCT_AB_COOP_WAVES_MAX
+#define PCT_AB_COOP_WAVES_MAX 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_COOP_WAVES, PCT_AB_COOP_WAVES_MAX))) void nn_grid_coop_kernel(GridDesc G, const float4 *__restrict__ pts,
                                                            const uint32_t *__restrict__ cell_start,
                                                            const float *__restrict__ q, uint32_t Q, uint32_t index_base,
                                                            const float4 *__restrict__ qsorted,

@@ -576,10 +576,14 @@ __device__ __forceinline__ void pyr_commit_work(uint32_t npts, uint32_t nruns, u
 }
 
 #ifndef PCT_AB_PYR_WAVES
-#define PCT_AB_PYR_WAVES 6      // VALU-issue-bound: 6 waves per SIMD with up to 80 VGPRs beat 7-8 with 64-72 (1.17 vs 1.11e9 q/s on the 10 M pillar cloud)
+#define PCT_AB_PYR_WAVES 6      // minimum 6, maximum 8: the current text lands at 63 VGPRs = 8 waves; CAPPING it at 7 / 6 / 5 waves per SIMD gives
+                                // 1.14 / 1.07 / 0.97e9 q/s against 1.19-1.20e9 on the 10 M pillar cloud (profiles/r03_ab_occupancy_cap.txt)
 #endif
 template <bool COUNT, bool FAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_PYR_WAVES, 8))) void nn_grid_pyr_kernel(GridDesc G, PyrDesc PD, const PyrNode *__restrict__ nodes, const unsigned char *__restrict__ hint,
+#ifndef PCT_AB_PYR_WAVES_MAX
+#define PCT_AB_PYR_WAVES_MAX 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_PYR_WAVES, PCT_AB_PYR_WAVES_MAX))) void nn_grid_pyr_kernel(GridDesc G, PyrDesc PD, const PyrNode *__restrict__ nodes, const unsigned char *__restrict__ hint,
                                                           const float4 *__restrict__ pts,
                                                           const uint32_t *__restrict__ cell_start, const float *__restrict__ q, uint32_t Q,
                                                           uint32_t index_base, const float4 *__restrict__ qsorted, uint32_t *__restrict__ out_idx,
