@@ -1595,8 +1595,10 @@ __device__ __forceinline__ double dpp_f64(double v)
 }
 
 // (measured on the dense batch kernel: the DPP form of the folds below costs registers -- 64 VGPRs + 16 bytes of scratch at 8 waves per
-// SIMD -- and the kernel ran 0.131 instead of 0.122 ms; with 7 waves per SIMD 0.128.  They stay on ds_bpermute; the pyramid walk,
-// which has registers to spare, uses the DPP forms: 1.06 against 1.09 ms.  gpurun_out logs r3_ab_dpp*.)
+// SIMD -- and the kernel ran 0.131 instead of 0.122 ms; at the present 7 waves / 72 VGPRs DPP folds + quad broadcasts of the run bounds
+// measure the same as ds_bpermute, 0.1161-0.1163 against 0.1166-0.1167 ms, as does reading a +inf pad record instead of clamping and
+// masking the slots beyond a run, 0.1156-0.1171 (profiles/r03_ab_dpp.txt).  They stay on ds_bpermute; the pyramid walk uses the DPP
+// forms: 1.06 against 1.09 ms.)
 __device__ __forceinline__ void coop_argmin8(double &d, uint32_t &i)
 {
 #pragma unroll
