@@ -387,7 +387,9 @@ int sort_into_cells(pct_cloud *c, const GridDesc &G, uint32_t **cell_start, size
         PCTCHK(dev_alloc(sorted, (size_t)n + kGridPad));         // + the inert records behind the last one (gb_pad_kernel)
         *sorted_cap = (size_t)n;
     }
-    gb_pad_kernel<<<1, 64, 0, s>>>(*sorted + n);
+#ifdef PCT_AB_OPEN_STAGE0
+    gb_pad_kernel<<<1, 64, 0, s>>>(*sorted + n);                  // only the open-ended stage 0 reads behind the last record
+#endif
     // ---- two-level counting sort on LDS histograms (gridbuild.hpp): no device-scope atomic per point ----
     static const bool lds_build = [] { const char *e = std::getenv("PCT_LDS_GRID_BUILD"); return e ? std::atoi(e) != 0 : true; }();
     // slabs of 2^s1 consecutive cells, sized for ~2-6 k points each (level 2 then holds a whole slab in LDS), at most kGbMaxSlabs;
