@@ -863,6 +863,9 @@ private:
                 const double d2 = kd_d2(T_.centre[nearest], qf);
                 bool overtaken = false;                               // a sphere added during this batch is strictly closer?
                 for (int32_t j = n0; j < n_now && !overtaken; j++) overtaken = kd_d2(T_.centre[untag(kdx_node_data(kd_, j))], qf) < d2;
+                // (answering just this sample on its own and replaying on -- as grow_staged does -- was measured on config C1: 9 launches
+                // instead of 43, but 333 single clearance launches for the samples a stale snapshot keeps losing to the spheres the batch
+                // itself adds: 7.7 ms against 2.4)
                 if (overtaken) break;
                 if (!T_.alive[nearest]) continue;                     // as the reference: skip the sample
                 n_clearance_++;

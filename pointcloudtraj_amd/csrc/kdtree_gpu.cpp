@@ -149,45 +149,83 @@ void run_destructors(kdtree *t)
     }
 }
 
-// Is node n visited by the reference's range walk for (q, range), and where?  `path` receives
-// one byte per edge from the root: 0 = the step went to the nearer child, 1 = to the farther
-// one.  Returns false when some far-side step has fabs(dx) >= range (kdtree.c:283).
-bool walk_path(const kdtree *t, int32_t n, const double *q, double range, std::vector<uint8_t> &path)
+// Is node n visited by the reference's range walk for (q, range), and where?  The walk position of a node is its root path, one step
+// per edge: NEAR = "into the nearer child", FAR = "into the farther one".  Returns false when some far-side step has
+// fabs(dx) >= range (kdtree.c:283: the walk never gets there).  Steps come out leaf-to-root in `steps`; their number in `depth`.
+enum : uint8_t { kStepNear = 1, kStepFar = 2 };       // 0 closes a path: an ancestor (a proper prefix) sorts before its descendants
+constexpr int kPackedDepth = 128;                      // steps that fit the packed key below
+// depth (>= 0, steps[0 .. depth) filled leaf-to-root, at most `cap` of them stored), or -1: pruned
+int walk_steps(const kdtree *t, int32_t n, const double *q, double range, uint8_t *steps, int cap)
 {
-    path.clear();
+    int depth = 0;
     for (int32_t c = n, a = t->parent[n]; a != NIL; c = a, a = t->parent[a]) {
         const int ax = t->axis[a];
         const double dx = q[ax] - t->pos[(size_t)t->dim * a + ax];
         const int32_t near_child = dx <= 0.0 ? t->lo[a] : t->hi[a];
-        if (c == near_child) path.push_back(0);
-        else {
-            if (!(std::fabs(dx) < range)) return false;
-            path.push_back(1);
+        uint8_t step = kStepNear;
+        if (c != near_child) {
+            if (!(std::fabs(dx) < range)) return -1;
+            step = kStepFar;
         }
+        if (depth < cap) steps[depth] = step;
+        depth++;
     }
-    std::reverse(path.begin(), path.end());
-    return true;
+    return depth;
 }
 
-// replay the reference walk's pruning (kdtree.c:283) and visit order over a list of in-range nodes
+// replay the reference walk's pruning (kdtree.c:283) and visit order over a list of in-range nodes.
+// Visit order = pre-order, nearer child before farther child = lexicographic order of the root paths with "path ends" < NEAR < FAR.
+// A path of up to 128 steps packs into four 64-bit words, two bits per step from the top: comparing the words compares the paths, and
+// an ordinary call (a few dozen hits) allocates nothing but its result -- the planner asks this once per RRT* sample
+// (corridor_finder.cpp:464).  Everything lives on the stack: queries on one tree may come from several threads, as with the
+// reference's double-precision entry points.  Deeper trees (a sorted insertion order can make them) take the byte-string form of the
+// same comparison.
 kdres *build_range_result(kdtree *t, const double *q, double range, const uint32_t *hits, int64_t nh)
 {
     kdres *r = new (std::nothrow) kdres();
     if (!r) return nullptr;
     r->tree = t;
+    struct Key { uint64_t w[4]; int32_t id; };
+    constexpr int kSmall = 96;
+    Key small[kSmall];
+    std::vector<Key> large;
+    Key *kept = small;
+    if (nh > kSmall) { large.resize((size_t)nh); kept = large.data(); }
+    int64_t nk = 0;
+    uint8_t steps[kPackedDepth];
+    bool deep = false;
+    for (int64_t i = 0; i < nh; i++) {
+        const int depth = walk_steps(t, (int32_t)hits[i], q, range, steps, kPackedDepth);
+        if (depth < 0) continue;
+        if (depth > kPackedDepth) { deep = true; break; }
+        Key &k = kept[nk++];
+        k.w[0] = k.w[1] = k.w[2] = k.w[3] = 0;
+        k.id = (int32_t)hits[i];
+        for (int pos = 0; pos < depth; pos++) k.w[pos >> 5] |= (uint64_t)steps[depth - 1 - pos] << (62 - 2 * (pos & 31));    // step `pos` from the root
+    }
+    if (!deep) {
+        std::sort(kept, kept + nk, [](const Key &a, const Key &b) {
+            for (int i = 0; i < 4; i++) if (a.w[i] != b.w[i]) return a.w[i] < b.w[i];
+            return false;
+        });
+        r->items.resize((size_t)nk);
+        for (int64_t i = 0; i < nk; i++) r->items[(size_t)i] = kept[nk - 1 - i].id;       // head insertion => reverse visit order
+        r->size = (int)nk;
+        return r;
+    }
     struct Hit { int32_t id; std::vector<uint8_t> path; };
-    std::vector<Hit> kept;
-    kept.reserve((size_t)nh);
-    std::vector<uint8_t> path;
-    for (int64_t i = 0; i < nh; i++)
-        if (walk_path(t, (int32_t)hits[i], q, range, path)) kept.push_back(Hit{ (int32_t)hits[i], path });
-    // pre-order, nearer child before farther child: an ancestor's path is a proper prefix of its
-    // descendants' and sorts first; siblings sort by their first differing step
-    std::sort(kept.begin(), kept.end(), [](const Hit &a, const Hit &b) {
+    std::vector<Hit> all;
+    all.reserve((size_t)nh);
+    std::vector<uint8_t> longsteps((size_t)t->count());
+    for (int64_t i = 0; i < nh; i++) {
+        const int depth = walk_steps(t, (int32_t)hits[i], q, range, longsteps.data(), (int)longsteps.size());
+        if (depth >= 0) all.push_back(Hit{ (int32_t)hits[i], std::vector<uint8_t>(longsteps.rend() - depth, longsteps.rend()) });
+    }
+    std::sort(all.begin(), all.end(), [](const Hit &a, const Hit &b) {
         return std::lexicographical_compare(a.path.begin(), a.path.end(), b.path.begin(), b.path.end());
     });
-    r->items.reserve(kept.size());
-    for (size_t i = kept.size(); i-- > 0;) r->items.push_back(kept[i].id);   // head insertion => reverse visit order
+    r->items.reserve(all.size());
+    for (size_t i = all.size(); i-- > 0;) r->items.push_back(all[i].id);
     r->size = (int)r->items.size();
     return r;
 }
@@ -235,35 +273,58 @@ int64_t host_max_nodes()
     return g_host_max;
 }
 
-inline double node_d2(const kdtree *t, int64_t i, const double *q)      // kdtree.c:379-382
+// kdtree.c:379-382
+// the scan over the host copy, with the dimension known to the compiler (the planner's trees: DIM = 3)
+template <int DIM>
+inline double row_d2(const double *p, const double *q, int dim)
 {
-    if (t->dim == 3) {
-        const double dx = t->pos[3 * (size_t)i] - q[0], dy = t->pos[3 * (size_t)i + 1] - q[1], dz = t->pos[3 * (size_t)i + 2] - q[2];
+    if (DIM == 3) {
+        const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
         double s = dx * dx;
         s = s + dy * dy;
         s = s + dz * dz;
         return s;
     }
-    const double *p = &t->pos[(size_t)t->dim * i];
     double s = 0.0;
-    for (int k = 0; k < t->dim; k++) { const double d = p[k] - q[k]; s = s + d * d; }
+    for (int k = 0; k < dim; k++) { const double d = p[k] - q[k]; s = s + d * d; }
     return s;
 }
 
-int32_t host_nearest(const kdtree *t, const double *q)
+template <int DIM>
+int32_t host_nearest_dim(const kdtree *t, const double *q)
 {
     const int64_t n = t->count();
-    double best = node_d2(t, 0, q);
+    const int dim = t->dim;
+    const double *P = t->pos.data();
+    double best = row_d2<DIM>(P, q, dim);
     int64_t bi = 0, ties = 1;
     for (int64_t i = 1; i < n; i++) {
-        const double d = node_d2(t, i, q);
+        const double d = row_d2<DIM>(P + (size_t)dim * i, q, dim);
         if (d < best) { best = d; bi = i; ties = 1; }
         else if (d == best) ties++;
     }
     if (ties == 1) return (int32_t)bi;
     std::vector<uint32_t> tied;
-    for (int64_t i = 0; i < n; i++) if (node_d2(t, i, q) == best) tied.push_back((uint32_t)i);
+    for (int64_t i = 0; i < n; i++) if (row_d2<DIM>(P + (size_t)dim * i, q, dim) == best) tied.push_back((uint32_t)i);
     return reference_tie_winner(t, q, tied.data(), (int64_t)tied.size());
+}
+int32_t host_nearest(const kdtree *t, const double *q) { return t->dim == 3 ? host_nearest_dim<3>(t, q) : host_nearest_dim<0>(t, q); }
+
+// node numbers with d2 <= r2 into buf[0 .. cap); returns how many there are (more than cap: the caller repeats with room for all)
+template <int DIM>
+int64_t host_in_range_dim(const kdtree *t, const double *q, double r2, uint32_t *buf, int64_t cap)
+{
+    const int64_t n = t->count();
+    const int dim = t->dim;
+    const double *P = t->pos.data();
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++)
+        if (row_d2<DIM>(P + (size_t)dim * i, q, dim) <= r2) { if (m < cap) buf[m] = (uint32_t)i; m++; }
+    return m;
+}
+inline int64_t host_in_range(const kdtree *t, const double *q, double r2, uint32_t *buf, int64_t cap)
+{
+    return t->dim == 3 ? host_in_range_dim<3>(t, q, r2, buf, cap) : host_in_range_dim<0>(t, q, r2, buf, cap);
 }
 
 }  // namespace
@@ -444,10 +505,16 @@ struct kdres *kd_nearest_range(struct kdtree *t, const double *q, double range)
     const int64_t n = t->count();
     if (n == 0) return r;
     if (n <= host_max_nodes()) {                          // small node set: the in-range nodes from a host scan, then the same replay
-        std::vector<uint32_t> hits;
         const double r2 = range * range;                  // kdtree.c:273: dist_sq <= SQ(range)
-        for (int64_t i = 0; i < n; i++) if (node_d2(t, i, q) <= r2) hits.push_back((uint32_t)i);
-        kdres *out = build_range_result(t, q, range, hits.data(), (int64_t)hits.size());
+        uint32_t few[256];                                // (one call per RRT* sample: the ordinary call allocates nothing here)
+        int64_t m = host_in_range(t, q, r2, few, 256);
+        kdres *out;
+        if (m <= 256) out = build_range_result(t, q, range, few, m);
+        else {
+            std::vector<uint32_t> many((size_t)m);
+            m = host_in_range(t, q, r2, many.data(), m);
+            out = build_range_result(t, q, range, many.data(), m);
+        }
         delete r;
         return out;
     }
