@@ -614,10 +614,13 @@ int upload_range(pct_cloud *c, const void *pts, int64_t n, int64_t stride, int64
 // Streaming kernels are grid-stride: at most 4 blocks of 256 threads per CU (16 waves per CU),
 // so the whole grid is resident in ONE round whatever the kernel's register count -- a grid of
 // 8 blocks per CU ran as 7 + 1 rounds at 66 VGPRs and cost almost 2x.
-int stream_blocks(int64_t n)
+// Q: the batch's size where the caller knows it (0 = unknown).  One or two queries against a DRAM-resident cloud do better with half the
+// waves: 512 blocks (2 waves per SIMD) read 100 M points at 0.78-0.80 of the 8 TB/s peak, 1024 at 0.74-0.77, 2048 at 0.72-0.73
+// (scripts/probe_stream.py; Q = 4 and the Infinity-Cache-sized 10 M-point cloud are the other way round or level).
+int stream_blocks(int64_t n, int64_t Q = 0)
 {
-    const char *e = std::getenv("PCT_STREAM_BLOCKS");      // tuning knob for scripts/probe.py
-    const int cap = e ? std::max(1, std::min(kMaxParts, std::atoi(e))) : 1024;
+    const char *e = std::getenv("PCT_STREAM_BLOCKS");      // tuning knob for scripts/probe.py, scripts/probe_stream.py
+    const int cap = e ? std::max(1, std::min(kMaxParts, std::atoi(e))) : ((Q == 1 || Q == 2) && n >= (1ll << 25) ? 512 : 1024);
     const int64_t groups = std::max<int64_t>(n >> 2, 1);
     return (int)std::min<int64_t>(cap, (groups + 255) / 256);
 }
@@ -698,7 +701,7 @@ int nn_stream_q64_slice(pct_cloud *c, int64_t qoff, int64_t Q, uint32_t *d_idx, 
     const double *d_q64 = c->d_q64 + 3 * qoff;
     d_idx += qoff;
     d_d2 += qoff;
-    const int blocks = stream_blocks(c->count);
+    const int blocks = stream_blocks(c->count, Q);
     begin_timing(c, s);
     dom_begin(c, s);
     for (int64_t q0 = 0; q0 < Q;) {
