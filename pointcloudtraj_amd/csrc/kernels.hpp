@@ -2104,8 +2104,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_COOP
     }
 }
 
-// Cooperative radius count: 8 lanes per query, the rows of the ball's bounding box taken four at a time -- four lanes fetch
-// the four run bounds at once, then every lane has two 16-byte loads per row in flight (16 points per row for the group)
+// Cooperative radius count: 8 lanes per query, the rows of the ball's bounding box: the run bounds of up to 16 rows fetched at once
+// (two per lane), then the rows two at a time, every lane with four 16-byte loads per row in flight (32 points per row for the group)
 // before the first compare; longer rows finish in a tail loop.  Every distance is the exact fp64 one (kdtree.c:273,
 // d2 <= r*r inclusive).  The box is [q - r - pad, q + r + pad] with pad = h/100: a point within r of q can only sit in a
 // cell of that range, because the fp32 cell assignment errs by < 4e-4 cells (same argument as cube_bound's h/256 slack).
@@ -2138,39 +2138,53 @@ __global__ __launch_bounds__(256) void count_grid_coop_kernel(GridDesc G, const 
         const int z0 = cell_coord(qzf - pad, G.oz, G.inv_h, G.gz), z1 = cell_coord(qzf + pad, G.oz, G.inv_h, G.gz);
         const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
         uint32_t c = 0;
-        for (int base = 0; base < nrows; base += 4) {
-            uint32_t rs[4], re[4];
-            {
-                const int k = base + ((int)sub & 3);              // lanes 4..7 repeat lanes 0..3 (same addresses)
+        // Rows of the box: the run bounds of up to 16 rows in ONE trip (two per lane), then the rows two at a time with 32 points of each
+        // in flight (a row of 3-4 cells holds ~20): a query's 9-16 rows cost 1 + rows/2 dependent round trips.  (The first form took the
+        // rows four at a time with 16 points each and finished every row in a tail loop, one trip per row: ~18 trips; 1 M counts of r = 1 on
+        // the 10 M-point cloud 0.51 -> 0.43 ms, profiles/r03_ab_count_rows.txt.)
+        for (int base = 0; base < nrows; base += 16) {
+            uint32_t bs[2], be[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = base + 8 * h + (int)sub;
                 const bool ok = k < nrows;
                 const uint32_t row = ok ? cell_lin(G, 0, y0 + k % ny, z0 + k / ny) : 0u;
                 const uint32_t a = cell_start[row + x0], b = cell_start[row + x1 + 1];
-                const uint32_t my_s = a, my_e = ok ? b : a;
-                if (COUNT && sub < 4) { npts += my_e - my_s; nruns += ok ? 1u : 0u; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) { rs[j] = (uint32_t)__shfl((int)my_s, j, kCoop); re[j] = (uint32_t)__shfl((int)my_e, j, kCoop); }
-            }
-            float4 P[4][2];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t last = re[j] > rs[j] ? re[j] - 1 : 0u;
-                P[j][0] = pts[min(rs[j] + sub, last)];
-                P[j][1] = pts[min(rs[j] + sub + kCoop, last)];
+                bs[h] = a; be[h] = ok ? b : a;
+                if (COUNT) { npts += be[h] - bs[h]; nruns += ok ? 1u : 0u; }
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int i = 0; i < 8; i++) {                         // rows base + 2 i, base + 2 i + 1
+                if (base + 2 * i >= nrows) break;                 // uniform within the group of 8 lanes
+                uint32_t rs[2], re[2];
 #pragma unroll
-                for (int d = 0; d < 2; d++) {
-                    const bool in = rs[j] + sub + kCoop * d < re[j];
-                    c += (in && dist2((double)P[j][d].x, (double)P[j][d].y, (double)P[j][d].z, qx, qy, qz) <= r2) ? 1u : 0u;
+                for (int j = 0; j < 2; j++) {
+                    const int r = 2 * i + j;                      // compile-time: which register, which lane
+                    rs[j] = (uint32_t)__shfl((int)bs[r >> 3], r & 7, kCoop);
+                    re[j] = (uint32_t)__shfl((int)be[r >> 3], r & 7, kCoop);
                 }
-            }
+                float4 P[2][4];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const uint32_t last = re[j] > rs[j] ? re[j] - 1 : 0u;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) P[j][d] = pts[min(rs[j] + sub + kCoop * d, last)];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        const bool in = rs[j] + sub + kCoop * d < re[j];
+                        c += (in && dist2((double)P[j][d].x, (double)P[j][d].y, (double)P[j][d].z, qx, qy, qz) <= r2) ? 1u : 0u;
+                    }
+                }
 #pragma unroll 1
-            for (int j = 0; j < 4; j++)
-                for (uint32_t p = rs[j] + 2 * kCoop + sub; p < re[j]; p += kCoop) {
-                    const float4 Pp = pts[p];
-                    c += dist2((double)Pp.x, (double)Pp.y, (double)Pp.z, qx, qy, qz) <= r2 ? 1u : 0u;
-                }
+                for (int j = 0; j < 2; j++)
+                    for (uint32_t p = rs[j] + 4 * kCoop + sub; p < re[j]; p += kCoop) {
+                        const float4 Pp = pts[p];
+                        c += dist2((double)Pp.x, (double)Pp.y, (double)Pp.z, qx, qy, qz) <= r2 ? 1u : 0u;
+                    }
+            }
         }
 #pragma unroll
         for (int off = 1; off < kCoop; off <<= 1) c += (uint32_t)__shfl_xor((int)c, off, kWave);
