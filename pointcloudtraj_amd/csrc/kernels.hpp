@@ -1840,6 +1840,42 @@ __device__ __forceinline__ void coop_nn_search(const GridDesc &G, const float4 *
 // 9 lanes fetch the rows' bounds, every lane takes one point of each row (all nine loads in flight), one 6-step fold over the 64
 // lanes, the exact winner.  The queries that even the cube does not decide (~1e-4) finish with the 8-lane shell walk as before.
 
+// Is a query still undecided after its 2x2x2 block [xa..xb] x [ya..yb] x [za..zb] gave best distance bd?  (f = the query's fractional
+// position in its cell (cx, cy, cz).)
+__device__ __forceinline__ bool block_leaves_undecided(const GridDesc &G, int cx, int cy, int cz, int xa, int xb, int ya, int yb, int za, int zb,
+                                                       float fx, float fy, float fz, double qx, double qy, double qz, double bd)
+{
+    // Quick accept in fp32 (the six fp64 face distances below cost ~6 of the kernel's 120 us): distances to the block's faces in cell
+    // units from the fractional position already at hand, the nearest one with cells behind it shortened by 1/64 cell -- far more
+    // than the fp32 rounding of fx (< 2e-4 cells) plus the exact test's own 1/256 slack -- so whatever passes here passes the exact
+    // test too; the ~2 % of queries in that 1/64-cell band, the undecided ones and queries outside the grid take the exact test.
+    {
+        const float inf = __builtin_huge_valf();
+        float bc = inf;
+        bc = fminf(bc, xa > 0 ? fx + (float)(cx - xa) : inf);
+        bc = fminf(bc, xb < G.gx - 1 ? (float)(xb + 1 - cx) - fx : inf);
+        bc = fminf(bc, ya > 0 ? fy + (float)(cy - ya) : inf);
+        bc = fminf(bc, yb < G.gy - 1 ? (float)(yb + 1 - cy) - fy : inf);
+        bc = fminf(bc, za > 0 ? fz + (float)(cz - za) : inf);
+        bc = fminf(bc, zb < G.gz - 1 ? (float)(zb + 1 - cz) - fz : inf);
+        // only for queries inside the grid (|f| small): the error bound above is for coordinates of at most ~1024 cells
+        if (bc < inf && fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) < 2.0f) {
+            const double b = (double)((bc - 0.015625f) * (float)G.hd * 0.999999f);
+            if (b > 0.0 && bd <= b * b) return false;
+        }
+    }
+    double bound = __builtin_huge_val();
+    if (xa > 0) bound = fmin(bound, qx - (G.oxd + (double)xa * G.hd));
+    if (xb < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(xb + 1) * G.hd) - qx);
+    if (ya > 0) bound = fmin(bound, qy - (G.oyd + (double)ya * G.hd));
+    if (yb < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(yb + 1) * G.hd) - qy);
+    if (za > 0) bound = fmin(bound, qz - (G.ozd + (double)za * G.hd));
+    if (zb < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(zb + 1) * G.hd) - qz);
+    if (bound == __builtin_huge_val()) return false;              // the block covers the whole grid
+    bound -= G.hd * (1.0 / 256.0);                                // same slack as cube_bound (fp32 cell assignment)
+    return !(bound > 0.0 && bd <= bound * bound);
+}
+
 // stage 0 of coop_nn_search alone; returns true when the query is still undecided
 template <bool COUNT>
 __device__ __forceinline__ bool coop_stage0(const GridDesc &G, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start,
@@ -1881,35 +1917,7 @@ __device__ __forceinline__ bool coop_stage0(const GridDesc &G, const float4 *__r
 #else
     coop_screen_rows<4, 2>(pts, rs, re, sub, qxf, qyf, qzf, qx, qy, qz, bd, bi);
 #endif
-    // Quick accept in fp32 (the six fp64 face distances below cost ~6 of the kernel's 120 us): distances to the block's faces in cell
-    // units from the fractional position already at hand, the nearest one with cells behind it shortened by 1/64 cell -- far more
-    // than the fp32 rounding of fx (< 2e-4 cells) plus the exact test's own 1/256 slack -- so whatever passes here passes the exact
-    // test too; the ~2 % of queries in that 1/64-cell band, the undecided ones and queries outside the grid take the exact test.
-    {
-        const float inf = __builtin_huge_valf();
-        float bc = inf;
-        bc = fminf(bc, xa > 0 ? fx + (float)(cx - xa) : inf);
-        bc = fminf(bc, xb < G.gx - 1 ? (float)(xb + 1 - cx) - fx : inf);
-        bc = fminf(bc, ya > 0 ? fy + (float)(cy - ya) : inf);
-        bc = fminf(bc, yb < G.gy - 1 ? (float)(yb + 1 - cy) - fy : inf);
-        bc = fminf(bc, za > 0 ? fz + (float)(cz - za) : inf);
-        bc = fminf(bc, zb < G.gz - 1 ? (float)(zb + 1 - cz) - fz : inf);
-        // only for queries inside the grid (|f| small): the error bound above is for coordinates of at most ~1024 cells
-        if (bc < inf && fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) < 2.0f) {
-            const double b = (double)((bc - 0.015625f) * (float)G.hd * 0.999999f);
-            if (b > 0.0 && bd <= b * b) return false;
-        }
-    }
-    double bound = __builtin_huge_val();
-    if (xa > 0) bound = fmin(bound, qx - (G.oxd + (double)xa * G.hd));
-    if (xb < G.gx - 1) bound = fmin(bound, (G.oxd + (double)(xb + 1) * G.hd) - qx);
-    if (ya > 0) bound = fmin(bound, qy - (G.oyd + (double)ya * G.hd));
-    if (yb < G.gy - 1) bound = fmin(bound, (G.oyd + (double)(yb + 1) * G.hd) - qy);
-    if (za > 0) bound = fmin(bound, qz - (G.ozd + (double)za * G.hd));
-    if (zb < G.gz - 1) bound = fmin(bound, (G.ozd + (double)(zb + 1) * G.hd) - qz);
-    if (bound == __builtin_huge_val()) return false;              // the block covers the whole grid
-    bound -= G.hd * (1.0 / 256.0);                                // same slack as cube_bound (fp32 cell assignment)
-    return !(bound > 0.0 && bd <= bound * bound);
+    return block_leaves_undecided(G, cx, cy, cz, xa, xb, ya, yb, za, zb, fx, fy, fz, qx, qy, qz, bd);
 }
 
 // the 3x3x3 cube around the cell of a WAVE-UNIFORM query, searched by all 64 lanes; every lane returns the same exact (bd, bi)
@@ -2021,6 +2029,32 @@ __device__ __forceinline__ void coop_finish_shells(const GridDesc &G, const floa
     }
 }
 
+// One query per group of 8 lanes, every lane of the wave in step (live = the group has a query): stage 0, then the whole wave on each
+// undecided query's cube in turn, then the 8-lane shell walk for what even the cube leaves open.  Every lane of a group returns its
+// query's exact (bd, bi).
+template <bool COUNT>
+__device__ __forceinline__ void coop_wave_search(const GridDesc &G, const float4 *__restrict__ pts, const uint32_t *__restrict__ cell_start, bool live,
+                                                 float qxf, float qyf, float qzf, uint32_t sub, double &bd, uint32_t &bi, uint32_t &npts, uint32_t &nruns)
+{
+    bd = __builtin_huge_val();
+    bi = kNoIndex;
+    bool undecided = false;
+    if (live) undecided = coop_stage0<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(undecided && sub == 0);
+    while (todo) {                                    // wave-uniform: one undecided query at a time, all 64 lanes on it
+        const int g = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float bx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qxf), g)),
+                    by = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qyf), g)),
+                    bz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qzf), g));
+        double cbd;
+        uint32_t cbi;
+        wave_cube_search<COUNT>(G, pts, cell_start, bx, by, bz, cbd, cbi, npts, nruns);
+        if (((threadIdx.x & 63) >> 3) == (uint32_t)(g >> 3)) { bd = cbd; bi = cbi; }
+    }
+    if (live && undecided) coop_finish_shells<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
+}
+
 template <bool COUNT, bool WAVE = false>
 // Occupancy target 7 waves per SIMD, as minimum AND maximum: with 8 allowed the scheduler keeps the kernel at 64 VGPRs by issuing the
 // eight record loads of stage 0 two at a time (four dependent round trips); capped at 7 it takes 72 VGPRs and issues all eight before the
@@ -2055,23 +2089,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PCT_AB_COOP
                 qxf = q[3 * t]; qyf = q[3 * t + 1]; qzf = q[3 * t + 2];
             }
         }
-        double bd = __builtin_huge_val();
-        uint32_t bi = kNoIndex;
-        bool undecided = false;
-        if (live) undecided = coop_stage0<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(undecided && sub == 0);
-        while (todo) {                                // wave-uniform: one undecided query at a time, all 64 lanes on it
-            const int g = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const float bx = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qxf), g)),
-                        by = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qyf), g)),
-                        bz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(qzf), g));
-            double cbd;
-            uint32_t cbi;
-            wave_cube_search<COUNT>(G, pts, cell_start, bx, by, bz, cbd, cbi, npts, nruns);
-            if (((threadIdx.x & 63) >> 3) == (uint32_t)(g >> 3)) { bd = cbd; bi = cbi; }
-        }
-        if (live && undecided) coop_finish_shells<COUNT>(G, pts, cell_start, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
+        double bd;
+        uint32_t bi;
+        coop_wave_search<COUNT>(G, pts, cell_start, live, qxf, qyf, qzf, sub, bd, bi, npts, nruns);
         if (live && sub == 0) {
             out_idx[t] = (bi == kNoIndex) ? kNoIndex : bi + index_base;
             out_d2[t] = bd;
