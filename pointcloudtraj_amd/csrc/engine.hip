@@ -780,15 +780,22 @@ int bin_queries(pct_cloud *c, const float *d_q, int64_t Q, hipStream_t s, const 
         // per step, same box), so the default keeps one slice size for both
         static const int hist_div = [] { const char *e = std::getenv("PCT_SORT_HIST_DIV"); return e ? std::max(1, std::min(8, std::atoi(e))) : 1; }();
         const uint32_t hist_per_block = std::max<uint32_t>(1024u, (per_block / (uint32_t)hist_div) / 1024u * 1024u);
-        qsort_hist_kernel<<<ceil_div(Q, (int64_t)hist_per_block), 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, hist_per_block, keys, total1, fill1,
-                                                                              pingpong ? total1_next : nullptr);
+        // 16-byte aligned query arrays are fetched four queries (three float4) at a time (kernels.hpp sort_load_items)
+        static const bool vec_on = [] { const char *e = std::getenv("PCT_SORT_VEC"); return e ? std::atoi(e) != 0 : true; }();
+        const bool vec = vec_on && (reinterpret_cast<uintptr_t>(d_q) & 15u) == 0;
+        if (vec) qsort_hist_kernel<true><<<ceil_div(Q, (int64_t)hist_per_block), 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, hist_per_block, keys, total1, fill1,
+                                                                                             pingpong ? total1_next : nullptr);
+        else qsort_hist_kernel<false><<<ceil_div(Q, (int64_t)hist_per_block), 1024, 0, s>>>(c->G, B, key_shift, lshift, d_q, (uint32_t)Q, hist_per_block, keys, total1, fill1,
+                                                                                           pingpong ? total1_next : nullptr);
         if (levels == 1) {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, need_perm ? c->d_perm : nullptr,
+            if (vec) qsort_scatter1_kernel<true><<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, need_perm ? c->d_perm : nullptr,
+                                                                    need_inv ? c->d_inv : nullptr, 1);
+            else qsort_scatter1_kernel<false><<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_qsorted, need_perm ? c->d_perm : nullptr,
                                                       need_inv ? c->d_inv : nullptr, 1);
             if (pingpong) c->sort_phase ^= 1;
             else HIPCHK(hipMemsetAsync(total1, 0, sizeof(uint32_t) * kSortBuckets, s));   // the fine pass would have re-zeroed it
         } else {
-            qsort_scatter1_kernel<<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr, nullptr, 0);
+            qsort_scatter1_kernel<false><<<nb, 1024, 0, s>>>(c->G, B, key_shift, keys, d_q, (uint32_t)Q, per_block, lshift, total1, fill1, start1, c->d_sortkey, c->d_sorttmp, nullptr, nullptr, 0);
             qsort_fine_kernel<<<kSortBuckets, kFineThreads, 0, s>>>(c->d_sortkey, c->d_sorttmp, start1, total1, (1u << lshift) - 1u, need_perm ? c->d_perm : nullptr,
                                                                     c->d_qsorted, need_inv ? c->d_inv : nullptr);
         }

@@ -1170,11 +1170,60 @@ constexpr int kSortBuckets = 1024;
 constexpr int kSortItems = 8;            // queries per thread in the level-1 kernels
 constexpr int kSortPerBlock = 1024 * kSortItems;      // most queries per block in the level-1 kernels (engine.hip picks 1024..8192 by batch size)
 
+// A thread's kSortItems queries of the level-1 kernels.  VEC (the query array is 16-byte aligned): the thread owns chunks of 4 CONSECUTIVE
+// queries and fetches each chunk as three float4 (48 contiguous bytes) instead of twelve dwords at a stride of 12 bytes: a quarter of the
+// load instructions.  Item k of thread `tid` is query sort_item<VEC>(base, k, tid); an item is live when sort_item_live says so.
+template <bool VEC>
+__device__ __forceinline__ uint32_t sort_item(uint32_t base, int k, uint32_t tid)
+{
+    return VEC ? base + 4u * (tid + 1024u * (uint32_t)(k >> 2)) + (uint32_t)(k & 3) : base + (uint32_t)k * 1024u + tid;
+}
+template <bool VEC>
+__device__ __forceinline__ bool sort_item_live(uint32_t base, int k, uint32_t tid, int items, uint32_t Q)
+{
+    if (VEC) return (tid + 1024u * (uint32_t)(k >> 2)) < 256u * (uint32_t)items && sort_item<true>(base, k, tid) < Q;
+    return k < items && sort_item<false>(base, k, tid) < Q;
+}
+template <bool VEC>
+__device__ __forceinline__ void sort_load_items(const float *__restrict__ q, uint32_t base, uint32_t tid, int items, uint32_t Q, float (&qv)[kSortItems][3])
+{
+    if (VEC) {
+#pragma unroll
+        for (int g = 0; g < kSortItems / 4; g++) {
+            const uint32_t t0 = sort_item<true>(base, 4 * g, tid);
+            if ((tid + 1024u * (uint32_t)g) < 256u * (uint32_t)items && t0 + 3u < Q) {       // base is a multiple of 1024: 3 * t0 floats = a multiple of 12
+                const float4 *v = reinterpret_cast<const float4 *>(q + 3 * (size_t)t0);
+                const float4 A = v[0], B = v[1], C = v[2];
+                qv[4 * g][0] = A.x; qv[4 * g][1] = A.y; qv[4 * g][2] = A.z;
+                qv[4 * g + 1][0] = A.w; qv[4 * g + 1][1] = B.x; qv[4 * g + 1][2] = B.y;
+                qv[4 * g + 2][0] = B.z; qv[4 * g + 2][1] = B.w; qv[4 * g + 2][2] = C.x;
+                qv[4 * g + 3][0] = C.y; qv[4 * g + 3][1] = C.z; qv[4 * g + 3][2] = C.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = 4 * g + j;
+                    const uint32_t t = sort_item<true>(base, k, tid);
+                    const bool ok = sort_item_live<true>(base, k, tid, items, Q);
+                    qv[k][0] = ok ? q[3 * (size_t)t] : 0.0f; qv[k][1] = ok ? q[3 * (size_t)t + 1] : 0.0f; qv[k][2] = ok ? q[3 * (size_t)t + 2] : 0.0f;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSortItems; k++) {
+            const uint32_t t = sort_item<false>(base, k, tid);
+            const bool ok = sort_item_live<false>(base, k, tid, items, Q);
+            qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
+        }
+    }
+}
+
 //
 // Three dependent launches per batch (hist -> scatter1 -> fine); at <= 256 K queries the sort is launch-latency-bound
 // (~40 us for five dependent operations, measured), so the bucket scan lives inside scatter1 and the two counter
 // arrays are re-zeroed without extra launches where possible: total1 is zero on entry (zeroed at allocation, then by the fine
 // kernel or, in single-level mode, a memset behind scatter1), fill1 is zeroed here, before any scatter1 block can touch it.
+template <bool VEC>
 __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B, int key_shift, int lshift, const float *__restrict__ q,
                                                           uint32_t Q, uint32_t per_block, uint32_t *__restrict__ keys,
                                                           uint32_t *__restrict__ total1, uint32_t *__restrict__ fill1,
@@ -1192,16 +1241,11 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
     const int items = (int)(per_block >> 10);             // per_block is a multiple of 1024, at most kSortPerBlock
     // all of a thread's queries are requested before the first is used: the loop used to pay one memory round trip per item
     float qv[kSortItems][3];
+    sort_load_items<VEC>(q, base, threadIdx.x, items, Q, qv);
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
-        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
-        const bool ok = k < items && t < Q;
-        qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < kSortItems; k++) {
-        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
-        if (k < items && t < Q) {
+        const uint32_t t = sort_item<VEC>(base, k, threadIdx.x);
+        if (sort_item_live<VEC>(base, k, threadIdx.x, items, Q)) {
             const uint32_t key = query_bin(G, B, qv[k][0], qv[k][1], qv[k][2]) >> key_shift;
             if (keys) keys[t] = key;                 // nullptr: the scatter pass recomputes the key from the query it reads anyway
             atomicAdd(&h[key >> lshift], 1u);
@@ -1215,6 +1259,7 @@ __global__ __launch_bounds__(1024) void qsort_hist_kernel(GridDesc G, BinDesc B,
 // level 1 scatter: the query record {x, y, z, bitcast(id)} travels with its key, so the fine pass
 // never gathers from the (randomly ordered) input again.  Every block scans the 1024 bucket totals itself
 // (thread i = bucket i) instead of waiting for a one-block scan kernel; block 0 publishes the starts for the fine pass.
+template <bool VEC>
 __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDesc B, int key_shift, const uint32_t *__restrict__ keys, const float *__restrict__ q,
                                                               uint32_t Q, uint32_t per_block, int lshift, const uint32_t *__restrict__ total1,
                                                               uint32_t *__restrict__ fill1, uint32_t *__restrict__ start1,
@@ -1249,11 +1294,11 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDes
     float qv[kSortItems][3];
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
-        const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
-        const bool ok = k < items && t < Q;
+        const uint32_t t = sort_item<VEC>(base, k, threadIdx.x);
+        const bool ok = sort_item_live<VEC>(base, k, threadIdx.x, items, Q);
         key[k] = ok ? (keys ? keys[t] : 0u) : 0xFFFFFFFFu;
-        qv[k][0] = ok ? q[3 * t] : 0.0f; qv[k][1] = ok ? q[3 * t + 1] : 0.0f; qv[k][2] = ok ? q[3 * t + 2] : 0.0f;
     }
+    sort_load_items<VEC>(q, base, threadIdx.x, items, Q, qv);
     if (!keys) {
 #pragma unroll
         for (int k = 0; k < kSortItems; k++)
@@ -1273,7 +1318,7 @@ __global__ __launch_bounds__(1024) void qsort_scatter1_kernel(GridDesc G, BinDes
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         if (key[k] != 0xFFFFFFFFu) {
-            const uint32_t t = base + (uint32_t)k * 1024u + threadIdx.x;
+            const uint32_t t = sort_item<VEC>(base, k, threadIdx.x);
             const uint32_t pos = basepos[key[k] >> lshift] + rank[k];
             if (!final_level) tmp_key[pos] = key[k];  // a fine pass follows and needs the key
             else if (perm) perm[pos] = t;             // single-level mode: this IS the final order; perm only for the kernels that read it
