@@ -1011,10 +1011,13 @@ def main():
         g = out["c1_stated_probe"]
         gpath = g.pop("_path")
         if O is not None:                                    # the CPU side only with the baseline leg
-            c = c1_stated_probe(E, O)
-            cpath = c.pop("_path")
-            c["same_corridor"] = bool(np.array_equal(cpath[0], gpath[0]) and np.array_equal(cpath[1], gpath[1]) and c.pop("status") == g["status"])
-            g["cpu_restatement"] = c
+            try:
+                c = c1_stated_probe(E, O)
+                cpath = c.pop("_path")
+                c["same_corridor"] = bool(np.array_equal(cpath[0], gpath[0]) and np.array_equal(cpath[1], gpath[1]) and c.pop("status") == g["status"])
+                g["cpu_restatement"] = c
+            except Exception as ex:      # noqa: BLE001
+                g["cpu_restatement"] = {"error": f"{type(ex).__name__}: {ex}"}
     print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()
