@@ -187,7 +187,7 @@ def c1_stated_probe(E, oracle_mod):
     return {"set_input_ms": c[0], "expansion_2000_ms": c[1], "cores": 1, "_path": c[2], "status": c[3]}
 
 
-def replan_probe(E, synth, ticks=200):
+def replan_probe(E, synth, ticks=200, clustered=False):
     """Config C5: rolling window of 5,000,000 points fed 50,000 per sensor frame (uniform in a 60 m
     cube around a drone moving +0.1 m per frame along x, seed 8), oldest frame evicted; the cloud keeps the rolling-map index
     (pct_cloud_ring_index: appends update it in place).  Per tick, through the host-buffer entry points (PCIe + launch
@@ -203,18 +203,19 @@ def replan_probe(E, synth, ticks=200):
     from pointcloudtraj_amd import scenarios as S
     window, frame = S.C5_WINDOW, S.C5_FRAME
     P = S.C5_PARAMS
+    c5_frame = S.c5_frame_clustered if clustered else S.c5_frame      # clustered: points on 0.1-lattice pillar faces, re-sensed frame after frame
     cloud = E.Cloud(window)
     cloud.ring_index()
     nfill = window // frame
     for k in range(nfill - 2):
-        cloud.append(S.c5_frame(k))
+        cloud.append(c5_frame(k))
     plan = E.ReplanPlan(cloud, S.C5_NODES, 128, S.C5_SEGMENTS)
     t_ing, t_rep, t_lib = [], [], []
     first_hits = 0
     gc.collect()
     gc.disable()                                   # a generation-2 collection of the interpreter (40 ms) used to land in one tick
     for k in range(nfill - 2, nfill + ticks):      # two untimed warm-up ticks (first launches)
-        new_frame = S.c5_frame(k)                  # the sensor's output: produced outside the timed region
+        new_frame = c5_frame(k)                  # the sensor's output: produced outside the timed region
         start, nodes, coef, T, od = S.c5_tick_queries(k)
         prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
         t0 = time.perf_counter()
@@ -230,7 +231,7 @@ def replan_probe(E, synth, ticks=200):
     t_zc, t_zc_rep = [], []
     buf = cloud.frame_buffer(frame)
     for k in range(nfill + ticks, nfill + ticks + max(20, ticks // 4)):
-        buf[:] = S.c5_frame(k)
+        buf[:] = c5_frame(k)
         start, nodes, coef, T, od = S.c5_tick_queries(k)
         prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
         t0 = time.perf_counter()
@@ -245,7 +246,8 @@ def replan_probe(E, synth, ticks=200):
     plan.close()
     tot = np.asarray(t_ing) + np.asarray(t_rep)
     pct = lambda a, q: float(np.percentile(a, q))
-    out = {"what": "C5: 5,000,000-point rolling cloud with the rolling-map index, +50,000 points per tick; per tick ONE captured hipGraph = "
+    out = {"what": ("C5, CLUSTERED variant (points on 0.1-lattice pillar faces, the same lattice points re-sensed every frame): " if clustered else "C5: ") +
+                   "5,000,000-point rolling cloud with the rolling-map index, +50,000 points per tick; per tick ONE captured hipGraph = "
                    "64 corridor-node inflations + 99-sample Bezier check + 21 control points; host buffers",
            "ticks": ticks, "ms_per_tick_p50": pct(tot, 50), "ms_per_tick_p99": pct(tot, 99),
            "ingest_ms_p50": pct(t_ing, 50), "ingest_ms_p99": pct(t_ing, 99), "replan_graph_ms_p50": pct(t_rep, 50), "replan_graph_ms_p99": pct(t_rep, 99),
@@ -260,7 +262,7 @@ def replan_probe(E, synth, ticks=200):
     cloud.ring_drop()
     t_old = []
     for k in range(ticks_total, ticks_total + 12):
-        new_frame = S.c5_frame(k)
+        new_frame = c5_frame(k)
         start, nodes, coef, T, od = S.c5_tick_queries(k)
         prm = E.inflate_params(start, P["sample_range"], P["search_margin"], P["max_radius"])
         t0 = time.perf_counter()
@@ -943,6 +945,7 @@ def main():
 
     if a.replan_probe and world == 1:
         guarded(out, "replan_probe", lambda: replan_probe(E, synth))
+        guarded(out, "replan_probe_clustered", lambda: replan_probe(E, synth, ticks=100, clustered=True))
         # corridor generation per replan (config C1 scenario: seed-6 pillar map seen from the start pose, clean_demo.launch constants,
         # fixed iteration counts 1500 / 400 / 200): safe-region RRT* on the engine, speculative batches, one fused launch per batch
         from pointcloudtraj_amd import corridor, scenarios

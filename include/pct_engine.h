@@ -113,6 +113,10 @@ int pct_cloud_ring_index(pct_cloud *c, float cell_size, const float extent[3]);
 int pct_cloud_ring_drop(pct_cloud *c);
 int pct_cloud_has_ring_index(const pct_cloud *c);
 int pct_cloud_ring_info(pct_cloud *c, int32_t dims[3], double *cell_size, int64_t *overflow_entries);
+/* records per bucket of the rolling-map index: 32 to begin with; doubled (up to 256, the window filed again) when more than ~1 % of the window
+ * sits in the overflow queue although the cells were sized from the window -- surfaces on a lattice finer than the cell, the same points sensed
+ * frame after frame (the reference's rgbd mode, camera_sensor.cpp:160-166).  0 = no rolling-map index. */
+int pct_cloud_ring_bucket_records(const pct_cloud *c);
 /* Zero-copy ingest.  pct_cloud_frame_buffer hands out a host-mapped staging buffer of at least `bytes` bytes (valid until the next
  * call that asks for a larger one, or pct_cloud_destroy); the producer -- a sensor driver, the deserialiser of a
  * sensor_msgs/PointCloud2 -- writes the frame's records there (x, y, z floats at the start of each stride-byte record) and

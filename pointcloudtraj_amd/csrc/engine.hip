@@ -223,6 +223,7 @@ struct pct_cloud {
     // rolling-map index (ring.hpp): bucket table that appends update in place
     bool ring_on = false, ring_ready = false;
     float ring_cell_req = 0.0f;
+    uint32_t ring_K = 32;                    // records per bucket of the rolling-map index (ring.hpp kRingK .. kRingKMax; grows when the overflow queue fills)
     float ring_extent_req[3] = { 0.0f, 0.0f, 0.0f };
     RingDesc R{};
     size_t ring_cells = 0;

@@ -26,13 +26,16 @@
 
 namespace pct {
 
-constexpr uint32_t kRingK = 32;                 // records per bucket (power of two)
+constexpr uint32_t kRingK = 32;                 // records per bucket the index starts with (RingDesc::K, a power of two; the host doubles it,
+constexpr uint32_t kRingKMax = 256;             // up to this, when the overflow queue shows that the window's cells hold more: surfaces on a
+                                                // lattice finer than the cell, the same points sensed again frame after frame)
 constexpr int kRingCellClamp = 1000000000;      // |cell coordinate| limit (non-finite / absurd coordinates land on the limit)
 
 struct RingDesc {
     double inv_h, h;
     int gx, gy, gz;          // bucket table dimensions, powers of two
     int lx, ly;              // log2(gx), log2(gy)
+    uint32_t K;              // records per bucket (power of two)
     // overflow queue capacity - 1.  The queue holds one entry per live spilled point plus dead entries its head has not passed yet;
     // the head is blocked only by a live entry, and entries behind a live head that are already dead can only belong to the same
     // insert launch as that head entry (younger launches are evicted later), so its length never exceeds capacity + one launch
@@ -88,10 +91,10 @@ __device__ __forceinline__ void ring_file(const RingDesc &R, float px, float py,
     const uint32_t h = ht[b].x;
     uint32_t t = __hip_atomic_load(&ht[b].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        if (t - h >= kRingK) break;                                 // full: overflow queue
+        if (t - h >= R.K) break;                                    // full: overflow queue
         const uint32_t seen = atomicCAS(&ht[b].y, t, t + 1u);
         if (seen == t) {
-            slots[(size_t)b * kRingK + (t & (kRingK - 1))] = rec;
+            slots[(size_t)b * R.K + (t & (R.K - 1))] = rec;
             where[slot] = t & ~kRingInOvf;
             return;
         }
@@ -133,12 +136,12 @@ __global__ __launch_bounds__(256) void ring_evict_kernel(RingDesc R, const float
             __hip_atomic_store(idw, kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             const uint32_t b = ring_bucket_of(R, x[slot], y[slot], z[slot]);
-            float4 *base = slots + (size_t)b * kRingK;
-            __hip_atomic_store(reinterpret_cast<uint32_t *>(&base[w & (kRingK - 1)].w), kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float4 *base = slots + (size_t)b * R.K;
+            __hip_atomic_store(reinterpret_cast<uint32_t *>(&base[w & (R.K - 1)].w), kRingDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tail = ht[b].y;
             uint32_t h = __hip_atomic_load(&ht[b].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             while (h != tail) {
-                const uint32_t *hw = reinterpret_cast<const uint32_t *>(&base[h & (kRingK - 1)].w);
+                const uint32_t *hw = reinterpret_cast<const uint32_t *>(&base[h & (R.K - 1)].w);
                 if (__hip_atomic_load(hw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != kRingDead) break;
                 const uint32_t seen = atomicCAS(&ht[b].x, h, h + 1u);
                 h = seen == h ? h + 1u : seen;
@@ -233,16 +236,18 @@ struct RingView {
     const RingState *st;
 };
 
-// all records of one bucket against the query, exact fp64, four loads in flight
-__device__ __forceinline__ void ring_scan_bucket(const RingView &V, uint32_t b, double qx, double qy, double qz, double &bd, uint32_t &bi)
+// the records of one bucket against the query, exact fp64, four loads in flight; the bucket is shared by `lanes` threads (a power of
+// two), thread `part` of them takes records 4 part .. 4 part + 3, then 4 lanes further on
+__device__ __forceinline__ void ring_scan_bucket(const RingView &V, uint32_t b, double qx, double qy, double qz, double &bd, uint32_t &bi,
+                                                 uint32_t part = 0, uint32_t lanes = 1)
 {
     const uint2 m = V.ht[b];
     const uint32_t n = m.y - m.x;
-    const float4 *base = V.slots + (size_t)b * kRingK;
-    for (uint32_t j = 0; j < n; j += 4) {
+    const float4 *base = V.slots + (size_t)b * V.R.K;
+    for (uint32_t j = 4u * part; j < n; j += 4u * lanes) {
         float4 P[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) P[k] = base[(m.x + min(j + (uint32_t)k, n - 1)) & (kRingK - 1)];     // tail repeats the last record
+        for (int k = 0; k < 4; k++) P[k] = base[(m.x + min(j + (uint32_t)k, n - 1)) & (V.R.K - 1)];     // tail repeats the last record
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const double d2 = dist2((double)P[k].x, (double)P[k].y, (double)P[k].z, qx, qy, qz);
@@ -271,11 +276,16 @@ __device__ __forceinline__ void ring_block_nn_search(const RingView &V, double p
     bi = kNoIndex;
     {   // overflow queue: exhaustive
         const uint32_t oh = V.st->ovf_head, on = V.st->ovf_tail - oh;
-        for (uint32_t k = threadIdx.x; k < on; k += 256) {
-            const float4 P = V.ovf[(oh + k) & R.ovf_mask];
-            const double d2 = dist2((double)P.x, (double)P.y, (double)P.z, qx, qy, qz);
-            const uint32_t id = __float_as_uint(P.w);
-            if (id != kRingDead && better(d2, id, bd, bi)) { bd = d2; bi = id; }
+        for (uint32_t k0 = threadIdx.x; k0 < on; k0 += 4u * 256u) {          // four records per thread in flight (a long queue is latency, not work)
+            float4 P[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) P[u] = V.ovf[(oh + min(k0 + 256u * (uint32_t)u, on - 1u)) & R.ovf_mask];    // beyond the end: the last entry again
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double d2 = dist2((double)P[u].x, (double)P[u].y, (double)P[u].z, qx, qy, qz);
+                const uint32_t id = __float_as_uint(P[u].w);
+                if (id != kRingDead && better(d2, id, bd, bi)) { bd = d2; bi = id; }
+            }
         }
     }
     bool wild = false;
@@ -290,16 +300,21 @@ __device__ __forceinline__ void ring_block_nn_search(const RingView &V, double p
         if (r == 1 || (!ox && was_x) || (!oy && was_y) || (!oz && was_z)) {
             // first cube, or an axis has just closed (or the query is wild): visit the whole box; buckets seen before are
             // merely seen again (a repeated (d2, slot) never changes the winner)
+            // few buckets (the first cube has 27): several threads share a bucket -- one thread per bucket leaves 229 of the block's
+            // threads idle while 27 walk their records four at a time, which is what a tick costs once the buckets are fat (surfaces,
+            // re-sensed points: 40-250 records per occupied bucket)
             const int total = nx * ny * nz;
-            for (int k = (int)threadIdx.x; k < total; k += 256) {
+            const int lanes = total <= 32 ? 8 : total <= 64 ? 4 : total <= 128 ? 2 : 1;
+            for (int k = (int)threadIdx.x / lanes; k < total; k += 256 / lanes) {
                 const int jx = k % nx, jy = (k / nx) % ny, jz = k / (nx * ny);
-                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi);
+                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi, threadIdx.x % (uint32_t)lanes, (uint32_t)lanes);
             }
         } else {
             // shell r: two z-faces, then two y-faces without the z-face rows, then two x-faces without either
             const int nyi = oy ? ny - 2 : ny, nzi = oz ? nz - 2 : nz;
             const int A = oz ? 2 * nx * ny : 0, B = oy ? 2 * nx * nzi : 0, Cc = ox ? 2 * nyi * nzi : 0;
-            for (int k = (int)threadIdx.x; k < A + B + Cc; k += 256) {
+            const int lanes = A + B + Cc <= 32 ? 8 : A + B + Cc <= 64 ? 4 : A + B + Cc <= 128 ? 2 : 1;
+            for (int k = (int)threadIdx.x / lanes; k < A + B + Cc; k += 256 / lanes) {
                 int jx, jy, jz;
                 if (k < A) {
                     const int f = k / (nx * ny), rem = k % (nx * ny);
@@ -311,7 +326,7 @@ __device__ __forceinline__ void ring_block_nn_search(const RingView &V, double p
                     const int k3 = k - A - B, f = k3 / (nyi * nzi), rem = k3 % (nyi * nzi);
                     jx = f ? nx - 1 : 0; jz = (oz ? 1 : 0) + rem / nyi; jy = (oy ? 1 : 0) + rem % nyi;
                 }
-                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi);
+                ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi, threadIdx.x % (uint32_t)lanes, (uint32_t)lanes);
             }
         }
         block_argmin256(bd, bi, s_d, s_i);

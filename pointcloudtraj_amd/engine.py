@@ -93,6 +93,7 @@ def lib():
         L.pct_nodeset_append.argtypes = [vp, C.POINTER(C.c_double), i64]
         L.pct_nodeset_nearest.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         L.pct_nodeset_radius_indices_r2.argtypes = [vp, C.POINTER(C.c_double), C.c_double, vp, i64, C.POINTER(i64)]
+        L.pct_cloud_ring_bucket_records.argtypes = [vp]
         L.pct_nn_batch.argtypes = [vp, f32p, i64, u32p, f64p]
         L.pct_nn_batch_algo.argtypes = [vp, i32, f32p, i64, u32p, f64p]
         L.pct_radius_count_batch.argtypes = [vp, f32p, f32p, i64, u32p]
@@ -285,7 +286,7 @@ class Cloud:
         h = C.c_double()
         ov = C.c_int64()
         _chk(lib().pct_cloud_ring_info(self._h, dims, C.byref(h), C.byref(ov)))
-        return dict(dims=tuple(dims), cell_size=h.value, overflow_entries=ov.value)
+        return dict(dims=tuple(dims), cell_size=h.value, overflow_entries=ov.value, bucket_records=int(lib().pct_cloud_ring_bucket_records(self._h)))
 
     def reserve_queries(self, Q: int):
         _chk(lib().pct_cloud_reserve_queries(self._h, int(Q)))

@@ -126,6 +126,30 @@ def c5_frame(k, frame=C5_FRAME, tunnel=0.0, step=0.1):
     return p
 
 
+def c5_frame_clustered(k, frame=C5_FRAME, step=0.1):
+    """sensor frame k of config C5's CLUSTERED variant (points on 0.1-grid pillar surfaces, as map_generator.cpp makes them): the
+    same window around the same moving drone, but every point lies on a face of a square pillar -- pillars on a 3 m lattice, 0.6-1.4 m wide by
+    a hash of their lattice cell, 0-6 m tall -- snapped to the 0.1 m lattice.  Frames re-sense the same surface points again and again (exact
+    duplicates across frames, as the reference's rgbd mode accumulates them, camera_sensor.cpp:160-166); the corridor along the flight
+    axis holds no pillar."""
+    u = synth.uniform01_f32(8, 3 * frame, offset=3 * k * frame).reshape(frame, 3).astype(np.float64)
+    v = synth.uniform01_f32(18, 2 * frame, offset=2 * k * frame).reshape(frame, 2).astype(np.float64)
+    x0 = step * k
+    px, py = u[:, 0] * 60.0 - 30.0 + x0, u[:, 1] * 60.0 - 30.0
+    ci, cj = np.floor(px / 3.0), np.floor(py / 3.0)                       # the pillar's lattice cell
+    cj = np.where(np.abs(cj * 3.0 + 1.5) <= 1.5, cj + np.where(py >= 0, 1.0, -1.0), cj)     # the two rows beside the flight axis move out: |y| < 3.8 m stays free
+    hsh = (ci.astype(np.int64) * 73856093) ^ (cj.astype(np.int64) * 19349663)
+    w = 0.6 + 0.1 * ((hsh >> 3) & 7).astype(np.float64)                   # 0.6 .. 1.3 m
+    cx, cy = ci * 3.0 + 1.5, cj * 3.0 + 1.5
+    face = (u[:, 2] * 4.0).astype(np.int64) & 3
+    along = (v[:, 0] - 0.5) * w
+    x = np.where(face == 0, cx - w / 2, np.where(face == 1, cx + w / 2, cx + along))
+    y = np.where(face == 2, cy - w / 2, np.where(face == 3, cy + w / 2, cy + along))
+    z = v[:, 1] * 6.0
+    p = np.stack([x, y, z], 1)
+    return (np.round(p * 10.0) / 10.0).astype(np.float32)
+
+
 def c5_tick_queries(k):
     """what tick k asks of the cloud: the drone's pose, 64 corridor-node centres ahead of it (seed 9) and the committed
     trajectory -- 3 segments of order 6, 1 s each, control points jittered by +-0.3 m (seed 9) around a straight 12 m run;

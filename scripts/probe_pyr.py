@@ -9,6 +9,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "pillar10m"
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1_048_576
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 pts = {"pillar": synth.pillar_map, "clustered2m": lambda: synth.clustered_points(62, 2_000_000, 0, 100), "pillar10m": lambda: synth.pillar_map_scaled(7.4),
+       "pillar100m": lambda: synth.pillar_map_scaled(23.2),          # config C4's size in the clustered variant, one card
        "uniform10m": lambda: synth.uniform_points(3, 10_000_000, 0, 100)}[name]()
 lo, hi = pts.min(0), pts.max(0)
 q = (lo + synth.uniform01_f32(77, 3 * Q).reshape(Q, 3) * (hi - lo)).astype(np.float32)

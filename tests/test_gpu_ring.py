@@ -134,19 +134,20 @@ def compare_tick(E, got, ref, nodes_n, want_nn, tag):
     return same
 
 
-def run_c5(E, oracle, window, frame, ticks, tunnel, want_nn, step=0.1):
+def run_c5(E, oracle, window, frame, ticks, tunnel, want_nn, step=0.1, clustered=False):
     c, m = E.Cloud(window), Mirror(window)
     c.ring_index()
     nfill = window // frame
+    make = (lambda k: S.c5_frame_clustered(k, frame, step)) if clustered else (lambda k: S.c5_frame(k, frame, tunnel, step))
     for k in range(nfill):
-        f = S.c5_frame(k, frame, tunnel, step)
+        f = make(k)
         c.append(f)
         m.append(f)
     plan = E.ReplanPlan(c, S.C5_NODES, 128, S.C5_SEGMENTS)
     hits = []
     P = S.C5_PARAMS
     for k in range(nfill, nfill + ticks):
-        f = S.c5_frame(k, frame, tunnel, step)
+        f = make(k)
         c.append(f)                                   # the plan stays valid: the ring index is updated in place
         m.append(f)
         start, nodes, coef, T, od = S.c5_tick_queries(k) if step == 0.1 else S.c5_tick_queries(int(round(k * step / 0.1)))
@@ -185,6 +186,38 @@ def test_replan_plan_c5_full_size(E, oracle):
     every radius / first hit / index against the exhaustive oracle on the same window"""
     hits = run_c5(E, oracle, S.C5_WINDOW, S.C5_FRAME, 20, tunnel=0.0, want_nn=True)
     assert len(hits) == 20
+
+
+@pytest.mark.parametrize("window,frame,ticks", [(300_000, 15_000, 6), (S.C5_WINDOW, S.C5_FRAME, 6)])
+def test_replan_plan_c5_clustered_variant(E, oracle, window, frame, ticks):
+    """"all clouds are also run in a clustered variant".  Config C5 with every point on a 0.1-lattice pillar face
+    (scenarios.c5_frame_clustered): surfaces instead of a filled volume, and the same lattice points sensed again frame after frame --
+    exact duplicates by the hundred thousand in the window, so ties (lowest ring slot wins) and the buckets' overflow handling carry the
+    result.  Every radius / first hit / index against the exhaustive oracle, in miniature and at the stated size."""
+    hits = run_c5(E, oracle, window, frame, ticks, tunnel=0.0, want_nn=True, clustered=True)
+    assert len(hits) == ticks
+
+
+def test_ring_buckets_grow_when_the_window_is_surfaces_and_duplicates(E, oracle):
+    """a window of lattice points on pillar faces, sensed again and again, puts far more than 32 records into the cells that hold any:
+    the index doubles its buckets (32 -> 64 -> ...) until the overflow queue -- which every query scans exhaustively -- is a small
+    share of the window again; answers stay those of the exhaustive oracle throughout"""
+    window, frame = 600_000, 20_000
+    c, m = E.Cloud(window), Mirror(window)
+    c.ring_index()
+    q = (synth.uniform_points(95, 400, -1, 1).astype(np.float64) * [25.0, 25.0, 3.0] + [3.0, 0.0, 3.0]).astype(np.float32)
+    worst = 0
+    for k in range(window // frame + 12):
+        f = S.c5_frame_clustered(k, frame)
+        c.append(f)
+        m.append(f)
+        if k % 6 == 5:
+            check_nn(E, c, m, q, oracle, f"frame {k}")           # ties among duplicates: lowest ring slot
+            worst = max(worst, c.ring_info()["overflow_entries"])
+    info = c.ring_info()
+    assert info["bucket_records"] > 32, info                         # the buckets have grown
+    assert info["overflow_entries"] < window // 64 + 4096, info      # and the queue is a small share of the window again
+    c.close()
 
 
 def test_replan_plan_c5_full_size_free_corridor(E, oracle):
