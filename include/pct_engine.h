@@ -106,9 +106,11 @@ int pct_cloud_append_aos(pct_cloud *c, const void *pts, int64_t n, int64_t strid
  * and ALGO_GRID; ALGO_STREAM still scans the whole window).  Results are the same as on any other cloud: exact fp64
  * distances, lowest ring slot on ties.  cell_size <= 0: chosen from the first data (about 6 points per cell at capacity);
  * extent (may be NULL): the window's size per axis, when the caller knows it (e.g. the sensing range) -- the table is then
- * allocated at once.  Memory: 512 B per bucket (32 records), buckets = the extent / cell_size per axis plus a quarter,
- * rounded up to powers of two; a cell holding more than 32 points spills to a queue every query scans exhaustively
- * (pct_cloud_ring_info reports its length).  Not available for small (host-mapped) clouds; excludes pct_cloud_build_grid. */
+ * allocated at once.  Memory: 512 B per bucket (32 records of 16 B), buckets = the extent / cell_size per axis plus a quarter,
+ * rounded up to powers of two; a cell holding more records than a bucket has room for spills to a queue every query scans
+ * exhaustively (pct_cloud_ring_info reports its length), and when that queue holds more than about 1 % of the window the buckets
+ * are doubled -- 64, 128, at most 256 records, 4 KiB per bucket, the table never beyond 32 GiB -- and the window is filed again
+ * (pct_cloud_ring_bucket_records).  Not available for small (host-mapped) clouds; excludes pct_cloud_build_grid. */
 int pct_cloud_ring_index(pct_cloud *c, float cell_size, const float extent[3]);
 int pct_cloud_ring_drop(pct_cloud *c);
 int pct_cloud_has_ring_index(const pct_cloud *c);
