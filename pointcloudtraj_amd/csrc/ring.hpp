@@ -257,6 +257,15 @@ __device__ __forceinline__ void ring_scan_bucket(const RingView &V, uint32_t b, 
     }
 }
 
+// threads that share one bucket of a step with `total` buckets: all 256 threads busy when the buckets are few; with grown buckets
+// (R.K > 32: the window's cells hold hundreds of records) also in the larger shells, where one thread per bucket would walk a fat
+// bucket alone while its neighbours have nothing to read
+__device__ __forceinline__ int ring_lanes_per_bucket(const RingDesc &R, int total)
+{
+    if (R.K > kRingK) return total <= 32 ? 8 : total <= 512 ? 4 : total <= 2048 ? 2 : 1;
+    return total <= 32 ? 8 : total <= 64 ? 4 : total <= 128 ? 2 : 1;
+}
+
 // Nearest point of the fp32-narrowed (px, py, pz) over a ring-indexed cloud; one 256-thread block, ONE THREAD PER BUCKET of the
 // cube / shell being examined (a bucket holds ~6 records: a thread reads its head/tail pair, then its records, four at a time),
 // block-wide fold after every shell.  stop_d2 as in block_nn_search (kernels.hpp): when only the radius is wanted the search may
@@ -304,7 +313,7 @@ __device__ __forceinline__ void ring_block_nn_search(const RingView &V, double p
             // threads idle while 27 walk their records four at a time, which is what a tick costs once the buckets are fat (surfaces,
             // re-sensed points: 40-250 records per occupied bucket)
             const int total = nx * ny * nz;
-            const int lanes = total <= 32 ? 8 : total <= 64 ? 4 : total <= 128 ? 2 : 1;
+            const int lanes = ring_lanes_per_bucket(R, total);
             for (int k = (int)threadIdx.x / lanes; k < total; k += 256 / lanes) {
                 const int jx = k % nx, jy = (k / nx) % ny, jz = k / (nx * ny);
                 ring_scan_bucket(V, ring_lin(R, x0 + jx, y0 + jy, z0 + jz), qx, qy, qz, bd, bi, threadIdx.x % (uint32_t)lanes, (uint32_t)lanes);
@@ -313,7 +322,7 @@ __device__ __forceinline__ void ring_block_nn_search(const RingView &V, double p
             // shell r: two z-faces, then two y-faces without the z-face rows, then two x-faces without either
             const int nyi = oy ? ny - 2 : ny, nzi = oz ? nz - 2 : nz;
             const int A = oz ? 2 * nx * ny : 0, B = oy ? 2 * nx * nzi : 0, Cc = ox ? 2 * nyi * nzi : 0;
-            const int lanes = A + B + Cc <= 32 ? 8 : A + B + Cc <= 64 ? 4 : A + B + Cc <= 128 ? 2 : 1;
+            const int lanes = ring_lanes_per_bucket(R, A + B + Cc);
             for (int k = (int)threadIdx.x / lanes; k < A + B + Cc; k += 256 / lanes) {
                 int jx, jy, jz;
                 if (k < A) {
